@@ -1,0 +1,213 @@
+#!/usr/bin/env python3
+"""bench.py -- the headline metric of BASELINE.json on MI355X.
+
+One STEP = one whole frame of the hot path: the reference's default scene
+(src/Object.hs:147-148) at 1920x1080, 1024 samples per pixel, maxBounces 8
+(BASELINE.json metric; configs[1]/[2]), with inputs (scene, canvas) already
+resident in HBM:
+    reset canvas -> pt_trace(spp / N on each of N GPUs, disjoint global sample
+    indices) -> [N > 1: ONE RCCL all-reduce (sum) of the fp32 canvas over xGMI]
+    -> fused RGB8 output kernel on rank 0.
+The total work per step is fixed as N grows, so "scaling" is "strong".
+
+value = closest-hit searches executed by all ranks in the timed steps / wall
+time (Mrays/s, a ray = one closestObjectTo, src/Lib.hs:81).  The searches are
+counted by the kernel itself; the per-pixel primary search is executed once per
+launch, not once per sample (the primary ray has no jitter, src/Lib.hs:41-51),
+and only executed searches are counted.
+
+Usage:  python bench.py [--gpus N] [--steps K] [--warmup W]
+        (N > 1: launched by torch.distributed.run, one rank per GPU)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP32_VALU_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (vector)"
+
+
+def flops_per_segment(objs):
+    """Algorithmic flops of one segment, SURVEY.md 8(d): 12 per plane test, 26
+    per disk test, + scatter (35 diffuse / 70 specular; sample-weighted by the
+    share of scattering objects of each kind)."""
+    from pathtracer_amd import Disk
+    f = sum(26 if isinstance(o.form, Disk) else 12 for o in objs)
+    scat = [70 if o.reflective else 35 for o in objs if not o.emittance > 0]
+    return f + (sum(scat) / len(scat) if scat else 0)
+
+
+def cpu_baseline(height, width, depth, bounces, threads, target_s=12.0):
+    """The oracle (CPU fp64 restatement of the reference, StdGen stream) timed
+    on this box's host cores on a bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle as O
+    p = O.params(height, width, depth, bounces, O.STDGEN)
+    tr = O.Tracer(p, O.default_scene(), threads=threads)
+    t0 = time.perf_counter()
+    tr.trace(1)
+    dt1 = time.perf_counter() - t0
+    spp = 1
+    more = int(max(0, min(64, target_s / max(dt1, 1e-3) - 1)))
+    if more:
+        tr.trace(more)
+        spp += more
+    dt = time.perf_counter() - t0
+    return {"value": round(tr.segments.value / dt / 1e6, 3), "unit": "Mrays/s", "cores": threads,
+            "kind": "port",
+            "sample": f"default scene {height}x{width}, {spp} spp, depth {bounces}: "
+                      f"{tr.segments.value} segments in {dt:.2f} s; fp64 C restatement of the reference "
+                      f"(oracle/pt_oracle.c, StdGen stream, OpenMP over rows), not the Haskell program"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--height", type=int, default=1920, help="Params.height = image width in pixels (F10)")
+    ap.add_argument("--width", type=int, default=1080, help="Params.width = image height in pixels (F10)")
+    ap.add_argument("--spp", type=int, default=1024)
+    ap.add_argument("--bounces", type=int, default=8)
+    ap.add_argument("--camera-depth", type=float, default=500.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--no-primary-reuse", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+
+    import torch
+    import pathtracer_amd as pa
+
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU: libpt has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    P = pa.Params(args.height, args.width, args.camera_depth, args.spp, args.bounces)
+    flags = pa.PT_FLAG_NO_PRIMARY_REUSE if args.no_primary_reuse else 0
+    r = pa.Renderer(P, pa.objects, seed=0, device=local_rank, sample_offset=rank, sample_stride=world,
+                    flags=flags)
+    stream = torch.cuda.current_stream()
+    r.set_stream(stream.cuda_stream)          # kernels, all-reduce and events share torch's stream
+    r.set_timing(True)
+
+    # the context's canvas as a torch tensor (no copy), for the all-reduce
+    ptr, nbytes = r.canvas_device_ptr()
+
+    class _Canvas:
+        __cuda_array_interface__ = {"shape": (nbytes // 4,), "typestr": "<f4", "data": (ptr, False),
+                                    "version": 2, "strides": None}
+    canvas = torch.as_tensor(_Canvas(), device=torch.device("cuda", local_rank))
+    rgb = torch.empty(args.height * args.width * 3, dtype=torch.uint8, device="cuda")
+
+    my_spp = args.spp // world + (1 if rank < args.spp % world else 0)
+
+    def step():
+        r.reset()
+        r.trace(my_spp)
+        if dist is not None:
+            dist.all_reduce(canvas, op=dist.ReduceOp.SUM)
+        if rank == 0:
+            r.rgb8_device(rgb.data_ptr(), pa.PT_RGB8_MEAN_CLAMP, args.spp)
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(max(args.warmup, 1)):       # at least one, to count a step's segments
+        step()
+    fence()
+    segs_step = torch.tensor([r.segments], dtype=torch.float64, device="cuda")
+    kernel_ms = []
+
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        kernel_ms.append(None)
+    fence()
+    elapsed = time.perf_counter() - t0
+
+    # kernel duration of the last timed step's trace launch(es), HIP events on the launch stream
+    ms_last, launches = r.last_trace_ms()
+    # a separate, individually event-timed pass for the roofline average
+    ev = []
+    for _ in range(min(args.steps, 5)):
+        r.reset()
+        r.trace(my_spp)
+        ev.append(r.last_trace_ms()[0])
+    fence()
+    kern_ms = sum(ev) / len(ev) / max(launches, 1)
+
+    t_el = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    if dist is not None:
+        dist.all_reduce(t_el, op=dist.ReduceOp.MAX)
+        dist.all_reduce(segs_step, op=dist.ReduceOp.SUM)
+    elapsed = float(t_el.item())
+    total_segs_step = float(segs_step.item())
+
+    if rank == 0:
+        value = total_segs_step * args.steps / elapsed / 1e6
+        F = flops_per_segment(pa.objects)
+        segs_launch_rank0 = r.segments / max(launches, 1)
+        achieved = F * segs_launch_rank0 / (kern_ms * 1e-3) / 1e12
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tpath) and world == 1:
+            try:
+                with open(tpath) as f:
+                    tj = json.load(f)
+                if tj.get("spp") == args.spp and tj.get("height") == args.height:
+                    traffic = tj.get("bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "Mrays/s (samples x bounces) at 1080p 1024spp",
+            "value": round(value, 1), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"reference default scene (4 objects), Params.height={args.height} "
+                                   f"Params.width={args.width} ({args.height}x{args.width} px image), "
+                                   f"{args.spp} spp, maxBounces {args.bounces}, cameraDepth {args.camera_depth:g}; "
+                                   f"sample-split over {world} GPU(s) + one RCCL all-reduce + RGB8 output",
+                       "segments_per_step": int(total_segs_step),
+                       "paths_per_step": args.height * args.width * args.spp,
+                       "primary_reuse": not args.no_primary_reuse,
+                       "parallelism": f"sample-split x{world}"},
+            "roofline": {"bound": "valu", "achieved": round(achieved, 3), "peak": FP32_VALU_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(achieved / FP32_VALU_PEAK_TFLOPS, 4),
+                         "traffic": traffic, "kernel": "trace_kernel", "kernel_ms": round(kern_ms, 4),
+                         "flops_per_segment": F, "segments_per_launch": int(segs_launch_rank0),
+                         "note": "fp32 VALU-bound path (no MFMA, ~0 HBM bytes per segment); peak = fp32 vector "
+                                 "157.3 TFLOP/s (= the fp32 MFMA peak)"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            threads = args.cpu_threads or int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
+            out["cpu_baseline"] = cpu_baseline(args.height, args.width, args.camera_depth, args.bounces, threads)
+        print(json.dumps(out), flush=True)
+
+    r.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,173 @@
+/*
+ * pt.h -- C ABI of libpt: the MI355X (gfx950) radiance loop of
+ * ethanabrooks/pathtracer behind plain C linkage.
+ *
+ * The reference is pure Haskell and has NO FFI or plugin interface of its own
+ * (SURVEY.md F2).  The seam this ABI replaces is the lazy list
+ *     Lib.traces :: [Array D DIM3 Double]            (src/Lib.hs:53-56)
+ * with its implicit inputs Params.* (src/Params.hs:3-11) and Object.objects
+ * (src/Object.hs:147-148), and its consumer Conversion.repa3ToImage
+ * (src/Conversion.hs:22-28).  A Haskell host binds these entry points with
+ * `foreign import ccall safe` (INTEGRATION.md shows the stub); every citation
+ * below names the reference code the entry point stands in for.
+ * All file:line citations are relative to the reference repository root.
+ *
+ * Conventions: every function returns PT_OK (0) or a negative pt_status and
+ * never throws or aborts across the boundary; all buffers are caller-allocated
+ * and the library never frees or keeps caller memory; a pt_ctx is bound to one
+ * GPU and is not thread-safe, distinct contexts are independent.  There is no
+ * CPU fallback: without a usable HIP device pt_create fails with
+ * PT_ERR_NO_DEVICE.
+ */
+#ifndef PT_H
+#define PT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PT_ABI_VERSION 1
+
+typedef enum {
+    PT_OK             =  0,
+    PT_ERR_INVALID    = -1,   /* bad argument (null pointer, size out of range) */
+    PT_ERR_NO_DEVICE  = -2,   /* no HIP device / device index out of range      */
+    PT_ERR_HIP        = -3,   /* a HIP runtime call failed; see pt_last_error   */
+    PT_ERR_NO_SCENE   = -4,   /* pt_trace / pt_primary_hits before pt_scene_upload */
+    PT_ERR_LIMIT      = -5    /* a documented limit exceeded (objects, samples, bounces) */
+} pt_status;
+
+/* Form constructors (src/Object.hs:51-56).  PT_SPHERE is an extension the
+ * reference only lists as a TODO (src/Object.hs:191-194); it has no reference
+ * parity. */
+enum { PT_INFINITE_PLANE = 0, PT_DISK = 1 };
+
+/* One Object with its Form flattened (src/Object.hs:30-36, :51-56).  Doubles,
+ * as the Haskell records hold; the library converts to its fp32 SoA layout at
+ * upload.  _name is not carried: the reference uses it only inside Eq Object
+ * (src/Object.hs:38-40), which the device replaces by index identity. */
+typedef struct {
+    int32_t kind;          /* PT_INFINITE_PLANE | PT_DISK                      */
+    int32_t reflective;    /* _reflective  (src/Object.hs:33)                  */
+    double  point[3];      /* _point / _center (src/Object.hs:52,55)           */
+    double  normal[3];     /* _normal, raw, not normalised (src/Object.hs:53,56) */
+    double  radius;        /* _radius, Disk only (src/Object.hs:54)            */
+    double  color[3];      /* _color       (src/Object.hs:31)                  */
+    double  emittance;     /* _emittance   (src/Object.hs:32)                  */
+} pt_object;
+
+/* Params.hs made a run-time value (src/Params.hs:3-11; numIters is the
+ * argument of pt_trace), plus what a counter-based RNG and a multi-GPU sample
+ * split need. */
+typedef struct {
+    int32_t  height;         /* Params.height (src/Params.hs:3)                 */
+    int32_t  width;          /* Params.width  (src/Params.hs:5)                 */
+    double   camera_depth;   /* Params.cameraDepth (src/Params.hs:7)            */
+    int32_t  max_bounces;    /* Params.maxBounces (src/Params.hs:11); 1..64     */
+    uint32_t seed;           /* Philox key (the reference seeds StdGen from 0, src/Lib.hs:34-39) */
+    int32_t  device;         /* HIP device ordinal                              */
+    int32_t  sample_offset;  /* this context renders global samples             */
+    int32_t  sample_stride;  /*   offset + k*stride, k = 0,1,...  (1-GPU: 0, 1) */
+    int32_t  flags;          /* PT_FLAG_*                                       */
+} pt_params;
+
+/* Trace every sample's primary segment in fp32 instead of reusing the
+ * per-pixel fp64 primary hit (the primary ray has no jitter, src/Lib.hs:41-51,
+ * so the hit is the same for every sample of a pixel). */
+#define PT_FLAG_NO_PRIMARY_REUSE 1
+
+typedef struct pt_ctx pt_ctx;
+
+/* Library / ABI identification. */
+int         pt_abi_version(void);
+const char *pt_status_string(int status);
+
+/* Replaces the compile-time constants of src/Params.hs:3-11 and the canvas
+ * set-up of src/Lib.hs:31-39 (blackCanvas, startingGens): allocates the fp32
+ * radiance-sum canvas (H*W*3, zeroed) on params->device. */
+int pt_create(pt_ctx **out, const pt_params *params);
+void pt_destroy(pt_ctx *ctx);
+
+/* Replaces the top-level value Object.objects (src/Object.hs:147-148).  Copies
+ * and flattens `n` objects to the device SoA; index order is preserved because
+ * closestObjectTo breaks ties by position (src/Lib.hs:84).  1 <= n <= 65536. */
+int pt_scene_upload(pt_ctx *ctx, const pt_object *objs, int32_t n);
+
+/* `iters` applications of traceCanvas (src/Lib.hs:58-65): adds `iters` more
+ * samples per pixel to the device canvas.  Sample indices continue from the
+ * running count, so k calls of 1 equal one call of k bit for bit.  Returns
+ * after the work is queued on the context's stream. */
+int pt_trace(pt_ctx *ctx, int32_t iters);
+
+/* Zero the canvas and the sample/segment counters (back to `traces !! 0`). */
+int pt_reset(pt_ctx *ctx);
+
+/* Element `samples_done` of Lib.traces (src/Lib.hs:53-56): the SUM (not mean)
+ * of all samples so far, out[(i*W + j)*3 + k], H*W*3 values
+ * (layout of fromTripleArray, src/Util.hs:63-67).  Synchronises. */
+int pt_read_sum(pt_ctx *ctx, double *out);
+int pt_read_sum_f32(pt_ctx *ctx, float *out);
+
+/* Conversion.repa3ToImage + listToPixelRGB8 (src/Conversion.hs:17-28):
+ * out[(j*H + i)*3 + k], an image H pixels wide and W pixels tall.
+ * PT_RGB8_REFERENCE: round-half-even(255 * sum), wrapped mod 256, no clamp, no
+ * division by the sample count -- what the reference does.
+ * PT_RGB8_MEAN_CLAMP: sum / samples, clamped to [0,1], then as above.
+ * PT_RGB8_MEAN_GAMMA: as MEAN_CLAMP with x^(1/2.2) before quantising. */
+enum { PT_RGB8_REFERENCE = 0, PT_RGB8_MEAN_CLAMP = 1, PT_RGB8_MEAN_GAMMA = 2 };
+int pt_read_rgb8(pt_ctx *ctx, uint8_t *out, int32_t mode);
+
+/* Parity hook for rayFromCamToPixel + closestObjectTo on the primary ray
+ * (src/Lib.hs:41-51, :81-98), evaluated in fp64 on the device: idx[i*W+j] is
+ * the struck object or -1; t its ray parameter; normal[3] the struck form's
+ * raw _normal (getNormal, src/Object.hs:180-183).  Any pointer may be NULL. */
+int pt_primary_hits(pt_ctx *ctx, int32_t *idx, double *t, double *normal);
+
+/* Counters: closestObjectTo executions (src/Lib.hs:81) so far, and samples
+ * per pixel added so far by this context. */
+int pt_segments(pt_ctx *ctx, uint64_t *out);
+int pt_samples_done(pt_ctx *ctx, int64_t *out);
+
+/* Device-side access for hosts that own GPU memory (torch, RCCL): the canvas
+ * device pointer (H*W*3 floats) for an all-reduce, the stream the context
+ * launches on, and a device-resident RGB8 image.  pt_set_stream takes a
+ * hipStream_t (NULL = the context's own stream). */
+int pt_canvas_device_ptr(pt_ctx *ctx, void **dptr, size_t *bytes);
+int pt_set_stream(pt_ctx *ctx, void *hip_stream);
+int pt_synchronize(pt_ctx *ctx);
+int pt_rgb8_device(pt_ctx *ctx, void *d_out, int32_t mode, int64_t samples_override);
+
+/* Host -> device canvas write, for the quantiser's parity test and for
+ * checkpoint/resume of (sum, samples_done). */
+int pt_write_sum_f32(pt_ctx *ctx, const float *in, int64_t samples_done);
+
+/* Device-function parity hooks: run the device's fp32 scatter / intersection
+ * code on `n` caller-supplied inputs (host arrays, 3 floats per vector).
+ *  pt_dev_diffuse : diffuse  (src/Lib.hs:129-132) with uniforms u1,u2.
+ *  pt_dev_specular: specular (src/Lib.hs:115-127), noise 40 unless noise>=0 given.
+ *  pt_dev_distance: distanceFrom (src/Object.hs:156-177) of rays against ONE
+ *                   object; t_out = NaN where the reference returns Nothing. */
+int pt_dev_diffuse(pt_ctx *ctx, int32_t n, const float *normal, const float *u, float *out);
+int pt_dev_specular(pt_ctx *ctx, int32_t n, const float *vector, const float *normal,
+                    const float *u, float noise, float *out);
+int pt_dev_distance(pt_ctx *ctx, int32_t n, const pt_object *obj, const float *origin,
+                    const float *vector, float *t_out);
+/* Philox2x32-10 on the device for ctr=(c0[k], c1[k]), key: out[2k], out[2k+1]. */
+int pt_dev_philox(pt_ctx *ctx, int32_t n, const uint32_t *c0, const uint32_t *c1,
+                  uint32_t key, uint32_t *out);
+
+/* Last kernel's launch duration in milliseconds, measured with HIP events on
+ * the context's stream around the most recent pt_trace (all its launches).
+ * Enabled by pt_set_timing(ctx, 1); synchronises when read. */
+int pt_set_timing(pt_ctx *ctx, int32_t enable);
+int pt_last_trace_ms(pt_ctx *ctx, float *ms, int32_t *launches);
+
+const char *pt_last_error(pt_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PT_H */

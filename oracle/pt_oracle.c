@@ -1,0 +1,498 @@
+/*
+ * pt_oracle.c -- CPU fp64 restatement of the reference's radiance loop.
+ * TEST INFRASTRUCTURE ONLY; see pt_oracle.h for what pins it and who may use it.
+ *
+ * Build with -ffp-contract=off: the reference is plain IEEE double arithmetic
+ * (GHC emits no fused multiply-adds), and the operation order below follows
+ * the Haskell source.
+ *
+ * All file:line citations are relative to /root/reference.
+ */
+#include "pt_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+static const double O_PI = 3.141592653589793;   /* Prelude pi :: Double */
+
+/* ------------------------------------------------------------------------ */
+/* Triple.hs                                                                 */
+/* ------------------------------------------------------------------------ */
+
+/* dot a b = tSum (a * b); tSum = sum . tripleToList, a left fold from 0
+ * (src/Triple.hs:39-50). */
+double o_dot(o_vec3 a, o_vec3 b)
+{
+    double s = 0.0;
+    s = s + a.x * b.x;
+    s = s + a.y * b.y;
+    s = s + a.z * b.z;
+    return s;
+}
+
+/* src/Triple.hs:52-59 */
+o_vec3 o_cross(o_vec3 a, o_vec3 b)
+{
+    o_vec3 r;
+    r.x = a.y * b.z - a.z * b.y;
+    r.y = a.z * b.x - a.x * b.z;
+    r.z = a.x * b.y - a.y * b.x;
+    return r;
+}
+
+/* norm2 = sqrt (x^2 + y^2 + z^2)  (src/Triple.hs:61-64) */
+double o_norm2(o_vec3 v)
+{
+    return sqrt(v.x * v.x + v.y * v.y + v.z * v.z);
+}
+
+/* normalize v = v / max (10 ** (-6)) (norm2 v)  (src/Triple.hs:66-69).
+ * Haskell's max x y = if x <= y then y else x. */
+o_vec3 o_normalize(o_vec3 v)
+{
+    double floor_ = pow(10.0, -6.0);
+    double n = o_norm2(v);
+    double norm = (floor_ <= n) ? n : floor_;
+    o_vec3 r = { v.x / norm, v.y / norm, v.z / norm };
+    return r;
+}
+
+/* ------------------------------------------------------------------------ */
+/* AC-Angle 1.0, Data.Angle: Degrees <-> Radians by x/180*pi and x/pi*180.   */
+/* (package not vendored; call sites src/Util.hs:24-25, src/Lib.hs:16)       */
+/* ------------------------------------------------------------------------ */
+static double deg2rad(double d) { return d / 180.0 * O_PI; }
+static double rad2deg(double r) { return r / O_PI * 180.0; }
+static double sine(double deg)   { return sin(deg2rad(deg)); }
+static double cosine(double deg) { return cos(deg2rad(deg)); }
+static double arccosine(double x)  { return rad2deg(acos(x)); }
+static double arctangent(double x) { return rad2deg(atan(x)); }
+
+/* Data.Fixed.mod' n d = n - fromInteger (floor (n / d)) * d, with the
+ * quotient's floor taken exactly.  For the only caller (arctan2, d = 360,
+ * |n| <= 270) an in-range n is returned unchanged, as the exact form does. */
+static double mod_prime_360(double n)
+{
+    if (n >= 0.0 && n < 360.0) return n;
+    return n - floor(n / 360.0) * 360.0;
+}
+
+/* ------------------------------------------------------------------------ */
+/* Util.hs                                                                   */
+/* ------------------------------------------------------------------------ */
+
+/* arctan2 x y (src/Util.hs:106-112).  x = -0.0 takes the x >= 0 branch and
+ * y / x keeps IEEE semantics (+-Inf, NaN). */
+double o_arctan2(double x, double y)
+{
+    double a = arctangent(y / x);
+    double a2;
+    if (x < 0.0)        a2 = a + 180.0;
+    else if (x >= 0.0)  a2 = a;
+    else                a2 = a;   /* x is NaN: Haskell would hit a pattern failure; unreachable on the path */
+    return mod_prime_360(a2);
+}
+
+/* src/Util.hs:114-122 */
+void o_to_spherical(o_vec3 vec, double *theta, double *phi)
+{
+    o_vec3 n = o_normalize(vec);
+    if (n.x == 0.0 && n.y == 0.0 && n.z >= 0.0) { *theta = 0.0;   *phi = 0.0; return; }
+    if (n.x == 0.0 && n.y == 0.0 && n.z <  0.0) { *theta = 180.0; *phi = 0.0; return; }
+    *theta = arccosine(n.z);
+    *phi   = o_arctan2(n.x, n.y);
+}
+
+/* src/Util.hs:124-129 */
+o_vec3 o_from_spherical(double theta, double phi)
+{
+    o_vec3 r;
+    r.x = cosine(phi) * sine(theta);
+    r.y = sine(phi) * sine(theta);
+    r.z = cosine(theta);
+    return r;
+}
+
+/* src/Util.hs:131-138.  Haskell's infix operators are left-associative, so
+ * a*b*x - c*y + d*e*z parses as (((a*b)*x) - (c*y)) + ((d*e)*z); unary minus
+ * in `-sine theta * x` negates the product. */
+o_vec3 o_rotate_abs(o_vec3 v, double theta, double phi)
+{
+    double ct = cosine(theta), st = sine(theta);
+    double cp = cosine(phi),   sp = sine(phi);
+    o_vec3 r;
+    r.x = ((ct * cp) * v.x - sp * v.y) + (st * cp) * v.z;
+    r.y = ((sp * ct) * v.x + cp * v.y) + (sp * st) * v.z;
+    r.z = -(st * v.x) + ct * v.z;
+    return r;
+}
+
+/* src/Util.hs:140-145 */
+o_vec3 o_rotate_rel(double theta, double phi, o_vec3 vector)
+{
+    o_vec3 local = o_from_spherical(theta, phi);
+    double t2, p2;
+    o_to_spherical(vector, &t2, &p2);
+    double length = o_norm2(vector);
+    o_vec3 r = o_rotate_abs(local, t2, p2);
+    r.x *= length; r.y *= length; r.z *= length;
+    return r;
+}
+
+/* ------------------------------------------------------------------------ */
+/* Object.hs                                                                 */
+/* ------------------------------------------------------------------------ */
+
+static o_vec3 v3(const double a[3]) { o_vec3 r = { a[0], a[1], a[2] }; return r; }
+static o_vec3 vsub(o_vec3 a, o_vec3 b) { o_vec3 r = { a.x - b.x, a.y - b.y, a.z - b.z }; return r; }
+static o_vec3 vadd(o_vec3 a, o_vec3 b) { o_vec3 r = { a.x + b.x, a.y + b.y, a.z + b.z }; return r; }
+static o_vec3 vmul(o_vec3 a, o_vec3 b) { o_vec3 r = { a.x * b.x, a.y * b.y, a.z * b.z }; return r; }
+static o_vec3 vscale(double s, o_vec3 a) { o_vec3 r = { s * a.x, s * a.y, s * a.z }; return r; }
+
+static void set_obj(o_object *o, int kind, int refl, double px, double py, double pz,
+                    double nx, double ny, double nz, double radius,
+                    double cr, double cg, double cb, double emit)
+{
+    memset(o, 0, sizeof *o);
+    o->kind = kind; o->reflective = refl;
+    o->point[0] = px; o->point[1] = py; o->point[2] = pz;
+    o->normal[0] = nx; o->normal[1] = ny; o->normal[2] = nz;
+    o->radius = radius;
+    o->color[0] = cr; o->color[1] = cg; o->color[2] = cb;
+    o->emittance = emit;
+}
+
+/* objects = [infPlane, infPlane2, infPlane3, light]  (src/Object.hs:104-148) */
+int o_default_scene(o_object *o)
+{
+    set_obj(&o[0], O_INFINITE_PLANE, 0, 20, -20, 100,  0, 0, -1, 0,  1.0, 1.0, 1.0, 0); /* :115-124 */
+    set_obj(&o[1], O_INFINITE_PLANE, 0, 20, -20, 100,  0, 1,  0, 0,  0.1, 1.0, 1.0, 0); /* :126-134 */
+    set_obj(&o[2], O_INFINITE_PLANE, 0, 20, -20, 100, -1, 0,  0, 0,  1.0, 1.0, 0.1, 0); /* :136-145 */
+    set_obj(&o[3], O_DISK,           1,  0,   0,  -1,  0, 0,  1, 20, 1.0, 1.0, 1.0, 2); /* :104-113 */
+    return 4;
+}
+
+/* src/Object.hs:151-153 */
+o_vec3 o_march(o_vec3 origin, o_vec3 vector, double t)
+{
+    return vadd(origin, vscale(t, vector));
+}
+
+static int plane_prime(o_vec3 origin, o_vec3 vector, o_vec3 point, o_vec3 normal, double *t)
+{
+    /* ((point - origin) `dot` normal) / (vector `dot` normalize normal)
+     * (src/Object.hs:176-177) -- raw normal above, unit normal below. */
+    *t = o_dot(vsub(point, origin), normal) / o_dot(vector, o_normalize(normal));
+    return 1;
+}
+
+/* guard (0 < distance && distance < 1/0)  (src/Object.hs:159) */
+static int guard_t(double t) { return (0.0 < t) && (t < INFINITY); }
+
+int o_distance_from_prime(o_vec3 origin, o_vec3 vector, const o_object *f, double *t)
+{
+    o_vec3 p = v3(f->point), n = v3(f->normal);
+    switch (f->kind) {
+    case O_INFINITE_PLANE:
+        return plane_prime(origin, vector, p, n, t);
+    case O_DISK: {
+        /* src/Object.hs:165-171: the inner plane test is the GUARDED distanceFrom */
+        double d;
+        plane_prime(origin, vector, p, n, &d);
+        if (!guard_t(d)) return 0;
+        o_vec3 hit = o_march(origin, vector, d);
+        double from_center = o_norm2(vsub(hit, p));
+        if (!(from_center < f->radius)) return 0;
+        *t = d;
+        return 1;
+    }
+    default:
+        return 0;   /* no such Form in the reference (src/Object.hs:51-61) */
+    }
+}
+
+/* src/Object.hs:156-160 */
+int o_distance_from(o_vec3 origin, o_vec3 vector, const o_object *f, double *t)
+{
+    double d;
+    if (!o_distance_from_prime(origin, vector, f, &d)) return 0;
+    if (!guard_t(d)) return 0;
+    *t = d;
+    return 1;
+}
+
+/* ------------------------------------------------------------------------ */
+/* System.Random 1.1 (StdGen)                                                */
+/* ------------------------------------------------------------------------ */
+
+/* mkStdGen s = mkStdGen32 (fromIntegral s); s' = s .&. maxBound;
+ * (q, s1) = s' `divMod` 2147483562; s2 = q `mod` 2147483398;
+ * StdGen (s1+1) (s2+1). */
+o_stdgen o_mk_stdgen(int64_t seed)
+{
+    int32_t s32 = (int32_t)(uint32_t)(uint64_t)seed;   /* Int -> Int32 keeps the low 32 bits */
+    int32_t s = s32 & 0x7fffffff;
+    int32_t q = s / 2147483562, s1 = s % 2147483562;   /* s >= 0: divMod == quotRem */
+    int32_t s2 = q % 2147483398;
+    o_stdgen g = { s1 + 1, s2 + 1 };
+    return g;
+}
+
+/* stdNext: L'Ecuyer's combined LCG with Schrage's decomposition. */
+int32_t o_stdgen_next(o_stdgen *g)
+{
+    int32_t s1 = g->s1, s2 = g->s2;
+    int32_t k  = s1 / 53668;
+    int32_t s1p = 40014 * (s1 - k * 53668) - k * 12211;
+    if (s1p < 0) s1p += 2147483563;
+    int32_t k2 = s2 / 52774;
+    int32_t s2p = 40692 * (s2 - k2 * 52774) - k2 * 3791;
+    if (s2p < 0) s2p += 2147483399;
+    int32_t z = s1p - s2p;
+    if (z < 1) z += 2147483562;
+    g->s1 = s1p; g->s2 = s2p;
+    return z;
+}
+
+/* randomIvalInteger (minBound, maxBound :: Int64): k = 2^64, b = 2147483562,
+ * target magnitude k*1000, so exactly three `next` calls;
+ * v = ((x1-1)*b + (x2-1))*b + (x3-1); result = minBound + v mod 2^64. */
+int64_t o_stdgen_random_int(o_stdgen *g)
+{
+    const unsigned __int128 b = 2147483562u;
+    unsigned __int128 v = 0;
+    for (int n = 0; n < 3; ++n) {
+        int32_t x = o_stdgen_next(g);
+        v = v * b + (unsigned __int128)(uint32_t)(x - 1);
+    }
+    uint64_t low = (uint64_t)v;
+    return (int64_t)(low ^ 0x8000000000000000ull);     /* -2^63 + (v mod 2^64) */
+}
+
+/* random :: Double = fromIntegral (mask53 .&. (x :: Int64)) / 2^53 */
+double o_stdgen_random_double(o_stdgen *g)
+{
+    int64_t x = o_stdgen_random_int(g);
+    uint64_t m = (uint64_t)x & ((1ull << 53) - 1);
+    return (double)m / 9007199254740992.0;
+}
+
+/* randomRFloating (l,h): swap if l > h; 2.0 * (0.5*l + coef * (0.5*h - 0.5*l)) */
+static double randomR_from_u(double u, double l, double h)
+{
+    if (l > h) { double tmp = l; l = h; h = tmp; }
+    return 2.0 * (0.5 * l + u * (0.5 * h - 0.5 * l));
+}
+
+double o_stdgen_randomR(o_stdgen *g, double l, double h)
+{
+    double u = o_stdgen_random_double(g);
+    return randomR_from_u(u, l, h);
+}
+
+/* ------------------------------------------------------------------------ */
+/* Philox2x32-10 (Random123): M = 0xD256D193, Weyl key bump 0x9E3779B9.      */
+/* ------------------------------------------------------------------------ */
+void o_philox2x32_10(uint32_t c0, uint32_t c1, uint32_t key, uint32_t out[2])
+{
+    for (int r = 0; r < 10; ++r) {
+        uint64_t prod = (uint64_t)0xD256D193u * (uint64_t)c0;
+        uint32_t hi = (uint32_t)(prod >> 32), lo = (uint32_t)prod;
+        c0 = hi ^ key ^ c1;
+        c1 = lo;
+        key += 0x9E3779B9u;
+    }
+    out[0] = c0; out[1] = c1;
+}
+
+static double u24(uint32_t x) { return (double)(x >> 8) * (1.0 / 16777216.0); }
+
+/* ------------------------------------------------------------------------ */
+/* Lib.hs                                                                    */
+/* ------------------------------------------------------------------------ */
+
+/* specular (src/Lib.hs:115-127) with the uniforms supplied. */
+o_vec3 o_specular_u(double u1, double u2, double noise, o_vec3 vector, o_vec3 normal)
+{
+    o_vec3 n1 = o_normalize(normal);
+    o_vec3 projection = vscale(o_dot(vector, n1), n1);
+    o_vec3 m2 = { -2.0, -2.0, -2.0 };
+    o_vec3 vprime = vadd(vector, vmul(m2, projection));
+    double angle_with_surface = 90.0 - arccosine(fabs(o_dot(n1, o_normalize(vector))));
+    double max_theta = (angle_with_surface <= noise) ? angle_with_surface : noise; /* min */
+    double theta = randomR_from_u(u1, 0.0, max_theta);
+    double phi   = randomR_from_u(u2, 0.0, 380.0);
+    return o_rotate_rel(theta, phi, vprime);
+}
+
+/* diffuse (src/Lib.hs:129-132): theta in (0,90), phi in (0,380) -- 380, not 360. */
+o_vec3 o_diffuse_u(double u1, double u2, o_vec3 normal)
+{
+    double theta = randomR_from_u(u1, 0.0, 90.0);
+    double phi   = randomR_from_u(u2, 0.0, 380.0);
+    return o_rotate_rel(theta, phi, normal);
+}
+
+/* rayFromCamToPixel (src/Lib.hs:41-51) */
+o_vec3 o_primary_direction(const o_params *p, int i, int j)
+{
+    double ip = (double)p->height / 2.0 - (double)i;
+    double jp = (double)j - (double)p->width / 2.0;
+    o_vec3 v = { ip, jp, p->camera_depth };
+    return o_normalize(v);
+}
+
+/* closestObjectTo (src/Lib.hs:81-98).  The reference removes the last-struck
+ * object by structural Eq (src/Object.hs:38-40, name included); object
+ * identity is the index here.  minimumBy keeps the EARLIER element on a tie
+ * (vector's min' x y = case cmp x y of GT -> y; _ -> x). */
+int o_closest_object_to(const o_object *objs, int n, o_vec3 origin, o_vec3 vector,
+                        int last, double *t_out)
+{
+    int best = -1; double best_t = 0.0;
+    for (int k = 0; k < n; ++k) {
+        if (k == last) continue;
+        double t;
+        if (!o_distance_from(origin, vector, &objs[k], &t)) continue;
+        if (best < 0 || t < best_t) { best = k; best_t = t; }   /* GT -> y only */
+    }
+    if (best >= 0) *t_out = best_t;
+    return best;
+}
+
+void o_primary_hits(const o_params *p, const o_object *objs, int n,
+                    int32_t *idx, double *t, double *normal)
+{
+    o_vec3 zero = { 0, 0, 0 };
+    for (int i = 0; i < p->height; ++i)
+        for (int j = 0; j < p->width; ++j) {
+            size_t px = (size_t)i * p->width + j;
+            double d = 0.0;
+            int k = o_closest_object_to(objs, n, zero, o_primary_direction(p, i, j), -1, &d);
+            idx[px] = k;
+            t[px] = (k >= 0) ? d : 0.0;
+            for (int c = 0; c < 3; ++c) normal[px * 3 + c] = (k >= 0) ? objs[k].normal[c] : 0.0;
+        }
+}
+
+/* startingGens (src/Lib.hs:34-39): mkStdGen <$> take (H*W) (randoms (mkStdGen 0)),
+ * row-major. */
+void o_starting_gens(const o_params *p, o_stdgen *gens)
+{
+    o_stdgen g = o_mk_stdgen(0);
+    size_t n = (size_t)p->height * p->width;
+    for (size_t k = 0; k < n; ++k) gens[k] = o_mk_stdgen(o_stdgen_random_int(&g));
+}
+
+typedef struct {
+    int mode; o_stdgen *gen; uint32_t pixel, seed; uint64_t sample; int bounce;
+} draw_state;
+
+/* randomRangeList gen [(0,a),(0,380)] (src/Util.hs:176-187): two sequential draws. */
+static void draw2(draw_state *d, double *u1, double *u2)
+{
+    if (d->mode == O_RNG_STDGEN) {
+        *u1 = o_stdgen_random_double(d->gen);
+        *u2 = o_stdgen_random_double(d->gen);
+    } else {
+        uint32_t out[2];
+        o_philox2x32_10(d->pixel, (uint32_t)((d->sample << 6) | (uint32_t)d->bounce), d->seed, out);
+        *u1 = u24(out[0]);
+        *u2 = u24(out[1]);
+    }
+}
+
+/* terminalColor (src/Lib.hs:67-79) as a loop; bounceRay/reflectVector
+ * (src/Lib.hs:101-113) inline.  Returns radiance of one sample. */
+static o_vec3 terminal_color(const o_params *p, const o_object *objs, int n,
+                             o_vec3 origin, o_vec3 vector, draw_state *d, uint64_t *segs)
+{
+    o_vec3 black = { 0, 0, 0 };
+    o_vec3 pixel = { 1, 1, 1 };          /* white, src/Lib.hs:64 */
+    int last = -1;
+    for (int left = p->max_bounces; left > 0; --left) {
+        double t;
+        ++*segs;
+        int k = o_closest_object_to(objs, n, origin, vector, last, &t);
+        if (k < 0) return black;                                    /* :72 */
+        const o_object *o = &objs[k];
+        if (o->emittance > 0.0) return vscale(o->emittance, pixel); /* :74 */
+        /* bounceRay (:101-106) */
+        o_vec3 hit = o_march(origin, vector, t);
+        double u1, u2;
+        draw2(d, &u1, &u2);
+        o_vec3 nrm = v3(o->normal);
+        o_vec3 nv = o->reflective ? o_specular_u(u1, u2, 40.0, vector, nrm)   /* :110 */
+                                  : o_diffuse_u(u1, u2, nrm);                 /* :111 */
+        pixel = vmul(pixel, v3(o->color));                                    /* :79 */
+        origin = hit; vector = nv; last = k;
+        d->bounce++;
+    }
+    return black;                                                             /* :68 */
+}
+
+void o_trace(const o_params *p, const o_object *objs, int n,
+             o_stdgen *gens, int64_t s_begin, int64_t iters, int64_t stride,
+             double *sum, double *sumsq, uint64_t *segments, int threads)
+{
+    uint64_t total = 0;
+    const int H = p->height, W = p->width;
+    if (stride < 1) stride = 1;
+#ifdef _OPENMP
+    if (threads < 1) threads = 1;
+#pragma omp parallel for schedule(dynamic, 4) num_threads(threads) reduction(+:total)
+#endif
+    for (int i = 0; i < H; ++i) {
+        for (int j = 0; j < W; ++j) {
+            size_t px = (size_t)i * W + j;
+            o_vec3 zero = { 0, 0, 0 };
+            o_vec3 dir = o_primary_direction(p, i, j);
+            for (int64_t it = 0; it < iters; ++it) {
+                draw_state d;
+                d.mode = p->rng; d.gen = gens ? &gens[px] : 0;
+                d.pixel = (uint32_t)px; d.seed = p->seed;
+                d.sample = (uint64_t)(s_begin + it * stride); d.bounce = 0;
+                uint64_t segs = 0;
+                o_vec3 c = terminal_color(p, objs, n, zero, dir, &d, &segs);
+                total += segs;
+                sum[px * 3 + 0] += c.x; sum[px * 3 + 1] += c.y; sum[px * 3 + 2] += c.z; /* :65 */
+                if (sumsq) {
+                    sumsq[px * 3 + 0] += c.x * c.x;
+                    sumsq[px * 3 + 1] += c.y * c.y;
+                    sumsq[px * 3 + 2] += c.z * c.z;
+                }
+            }
+        }
+    }
+    if (segments) *segments += total;
+    (void)threads;
+}
+
+/* ------------------------------------------------------------------------ */
+/* Conversion.hs                                                             */
+/* ------------------------------------------------------------------------ */
+
+/* round :: Double -> Word8 goes Double -> Int (round half to even) -> Word8
+ * (wrap mod 256).  No clamp, no gamma (src/Conversion.hs:17-20). */
+uint8_t o_to_word8(double x)
+{
+    double r = nearbyint(255.0 * x);      /* default rounding mode: ties to even */
+    return (uint8_t)(uint64_t)(int64_t)r;
+}
+
+/* generateImage fromCoords Params.height Params.width with
+ * fromCoords i j = canvas ! (i, j, k): the PNG is H wide, W tall, pixel
+ * (x=i, y=j) at byte (j*H + i)*3 (src/Conversion.hs:22-28). */
+void o_repa3_to_image(const o_params *p, const double *canvas, uint8_t *rgb)
+{
+    const int H = p->height, W = p->width;
+    for (int j = 0; j < W; ++j)
+        for (int i = 0; i < H; ++i)
+            for (int k = 0; k < 3; ++k)
+                rgb[((size_t)j * H + i) * 3 + k] = o_to_word8(canvas[((size_t)i * W + j) * 3 + k]);
+}

@@ -1,0 +1,16 @@
+"""pathtracer_amd -- MI355X-native radiance loop of ethanabrooks/pathtracer.
+
+The product is libpt.so (HIP kernels behind the C ABI of include/pt.h); this
+package is the thin host-side mirror of the reference's interface for that
+path.  Importing it loads libpt.so and fails loudly if it is missing.
+"""
+from . import _lib  # noqa: F401  (loads libpt.so or raises)
+from ._lib import (PT_FLAG_NO_PRIMARY_REUSE, PT_RGB8_MEAN_CLAMP, PT_RGB8_MEAN_GAMMA, PT_RGB8_REFERENCE,
+                   PtError)
+from .render import Renderer, repa3ToImage, traces
+from .scene import (Disk, InfinitePlane, Object, Params, disk, infLight, infPlane, infPlane2, infPlane3,
+                    light, objects, random_disk_scene)
+
+__all__ = ["Renderer", "traces", "repa3ToImage", "Params", "Object", "Disk", "InfinitePlane", "objects",
+           "infPlane", "infPlane2", "infPlane3", "light", "infLight", "disk", "random_disk_scene", "PtError",
+           "PT_RGB8_REFERENCE", "PT_RGB8_MEAN_CLAMP", "PT_RGB8_MEAN_GAMMA", "PT_FLAG_NO_PRIMARY_REUSE"]

@@ -1,0 +1,533 @@
+// pt_api.hip -- the C ABI of libpt (include/pt.h): context, scene flattening,
+// kernel launches, read-back.  No CPU fallback exists: every compute entry
+// point runs HIP kernels on the context's device or fails.
+//
+// File:line citations are relative to the reference repository root.
+#include "../../include/pt.h"
+#include "pt_internal.hpp"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <new>
+#include <string>
+#include <vector>
+
+using namespace pt;
+
+struct pt_ctx {
+    pt_params p{};
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    float *d_canvas = nullptr;
+    unsigned long long *d_segments = nullptr;
+    float4 *d_geom = nullptr, *d_mat = nullptr;
+    double *d_prim = nullptr;
+    uint8_t *d_rgb = nullptr;
+    int n_obj = 0;
+    bool has_specular = false;
+    StaticGeom sg{};
+    int64_t samples_done = 0;
+    bool timing = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int last_launches = 0;
+    bool have_timing = false;
+    std::string err;
+};
+
+namespace {
+
+thread_local std::string g_err;   // for failures before a context exists
+
+constexpr int64_t MAX_GLOBAL_SAMPLES = (int64_t)1 << 26;   // sample index shares a Philox word with a 6-bit bounce
+constexpr int     MAX_BOUNCES = 64;
+constexpr int     MAX_OBJECTS = 65536;
+constexpr int     MAX_SAMPLES_PER_LAUNCH = 4096;
+
+int fail(pt_ctx *c, int status, const std::string &msg)
+{
+    if (c) c->err = msg; else g_err = msg;
+    return status;
+}
+
+#define PT_HIP(c, call)                                                                      \
+    do {                                                                                     \
+        hipError_t e_ = (call);                                                              \
+        if (e_ != hipSuccess)                                                                \
+            return fail((c), PT_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+size_t npix(const pt_ctx *c) { return (size_t)c->p.height * (size_t)c->p.width; }
+
+// ---- host-side scene flattening (fp64, then rounded to fp32) ---------------
+// The per-object constants below are the wave-invariant part of
+// distanceFrom' (src/Object.hs:176-177) and of rotateRel about the object's
+// normal (src/Util.hs:140-145), evaluated once at upload in the reference's
+// own operation order.
+struct d3 { double x, y, z; };
+
+double norm2_(d3 v) { return std::sqrt(v.x * v.x + v.y * v.y + v.z * v.z); }   // src/Triple.hs:61-64
+
+d3 normalize_(d3 v)                                                            // src/Triple.hs:66-69
+{
+    const double fl = std::pow(10.0, -6.0);
+    const double n = norm2_(v);
+    const double nn = (fl <= n) ? n : fl;
+    return d3{v.x / nn, v.y / nn, v.z / nn};
+}
+
+const double kPi = 3.141592653589793;
+double sine_(double deg) { return std::sin(deg / 180.0 * kPi); }               // AC-Angle Degrees
+double cosine_(double deg) { return std::cos(deg / 180.0 * kPi); }
+
+// toSphericalCoords (src/Util.hs:114-122) with arctan2 (:106-112), degrees.
+void to_spherical_(d3 vec, double &theta, double &phi)
+{
+    const d3 n = normalize_(vec);
+    if (n.x == 0.0 && n.y == 0.0 && n.z >= 0.0) { theta = 0.0; phi = 0.0; return; }
+    if (n.x == 0.0 && n.y == 0.0 && n.z < 0.0) { theta = 180.0; phi = 0.0; return; }
+    theta = std::acos(n.z) / kPi * 180.0;
+    double a = std::atan(n.y / n.x) / kPi * 180.0;
+    if (n.x < 0.0) a += 180.0;
+    if (!(a >= 0.0 && a < 360.0)) a = a - std::floor(a / 360.0) * 360.0;       // `mod'` 360
+    phi = a;
+}
+
+void flatten_object(const pt_object &ob, float4 *geom3, float4 *mat4, double *prim)
+{
+    const d3 p{ob.point[0], ob.point[1], ob.point[2]};
+    const d3 n{ob.normal[0], ob.normal[1], ob.normal[2]};
+    const d3 nh = normalize_(n);
+    const double A = (0.0 + p.x * n.x + p.y * n.y) + p.z * n.z;
+    const bool disk = ob.kind == PT_DISK;
+    const float inf = std::numeric_limits<float>::infinity();
+    // a disk with a negative radius can never satisfy distance < radius
+    const float r2 = !disk ? inf : (ob.radius > 0.0 ? (float)(ob.radius * ob.radius) : -1.0f);
+    geom3[0] = make_float4((float)n.x, (float)n.y, (float)n.z, (float)A);
+    geom3[1] = make_float4((float)nh.x, (float)nh.y, (float)nh.z, r2);
+    geom3[2] = make_float4((float)p.x, (float)p.y, (float)p.z, 0.0f);
+
+    // M = |n| * rotateAbs(., theta', phi')  (src/Util.hs:131-145)
+    double th, ph;
+    to_spherical_(n, th, ph);
+    const double ct = cosine_(th), st = sine_(th), cp = cosine_(ph), sp = sine_(ph);
+    const double len = norm2_(n);
+    const double M[3][3] = {{ct * cp * len, -sp * len, st * cp * len},
+                            {sp * ct * len, cp * len, sp * st * len},
+                            {-st * len, 0.0, ct * len}};
+    const float e = ob.emittance > 0.0 ? (float)ob.emittance : (ob.reflective ? -1.0f : 0.0f);
+    mat4[0] = make_float4((float)ob.color[0], (float)ob.color[1], (float)ob.color[2], e);
+    mat4[1] = make_float4((float)M[0][0], (float)M[0][1], (float)M[0][2], (float)nh.x);
+    mat4[2] = make_float4((float)M[1][0], (float)M[1][1], (float)M[1][2], (float)nh.y);
+    mat4[3] = make_float4((float)M[2][0], (float)M[2][1], (float)M[2][2], (float)nh.z);
+
+    prim[0] = p.x; prim[1] = p.y; prim[2] = p.z;
+    prim[3] = n.x; prim[4] = n.y; prim[5] = n.z;
+    prim[6] = nh.x; prim[7] = nh.y; prim[8] = nh.z;
+    prim[9] = ob.radius;
+    prim[10] = disk ? 1.0 : 0.0;
+}
+
+template <typename T> struct DevBuf {
+    T *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t n) { return hipMalloc((void **)&p, n * sizeof(T)); }
+    hipError_t up(const T *h, size_t n) { return hipMemcpy(p, h, n * sizeof(T), hipMemcpyHostToDevice); }
+    hipError_t down(T *h, size_t n) { return hipMemcpy(h, p, n * sizeof(T), hipMemcpyDeviceToHost); }
+};
+
+int check_ctx(pt_ctx *c)
+{
+    if (!c) return fail(nullptr, PT_ERR_INVALID, "null context");
+    hipError_t e = hipSetDevice(c->p.device);
+    if (e != hipSuccess) return fail(c, PT_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
+    return PT_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int pt_abi_version(void) { return PT_ABI_VERSION; }
+
+const char *pt_status_string(int s)
+{
+    switch (s) {
+    case PT_OK: return "ok";
+    case PT_ERR_INVALID: return "invalid argument";
+    case PT_ERR_NO_DEVICE: return "no usable HIP device";
+    case PT_ERR_HIP: return "HIP runtime error";
+    case PT_ERR_NO_SCENE: return "no scene uploaded";
+    case PT_ERR_LIMIT: return "limit exceeded";
+    default: return "unknown status";
+    }
+}
+
+const char *pt_last_error(pt_ctx *ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
+
+int pt_create(pt_ctx **out, const pt_params *params)
+{
+    if (!out || !params) return fail(nullptr, PT_ERR_INVALID, "pt_create: null argument");
+    *out = nullptr;
+    const pt_params &p = *params;
+    if (p.height < 1 || p.width < 1 || (int64_t)p.height * p.width > ((int64_t)1 << 30))
+        return fail(nullptr, PT_ERR_INVALID, "pt_create: height/width out of range");
+    if (p.max_bounces < 1 || p.max_bounces > MAX_BOUNCES)
+        return fail(nullptr, PT_ERR_LIMIT, "pt_create: max_bounces must be in 1..64");
+    if (p.sample_stride < 1 || p.sample_offset < 0 || p.sample_offset >= p.sample_stride)
+        return fail(nullptr, PT_ERR_INVALID, "pt_create: need 0 <= sample_offset < sample_stride");
+    if (!(p.camera_depth == p.camera_depth))
+        return fail(nullptr, PT_ERR_INVALID, "pt_create: camera_depth is NaN");
+
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev < 1) {
+        (void)hipGetLastError();
+        return fail(nullptr, PT_ERR_NO_DEVICE, "pt_create: no HIP device (libpt has no CPU path)");
+    }
+    if (p.device < 0 || p.device >= ndev)
+        return fail(nullptr, PT_ERR_NO_DEVICE, "pt_create: device ordinal out of range");
+
+    pt_ctx *c = new (std::nothrow) pt_ctx;
+    if (!c) return fail(nullptr, PT_ERR_INVALID, "pt_create: out of host memory");
+    c->p = p;
+    auto bail = [&](const char *what, hipError_t he) {
+        std::string m = std::string(what) + ": " + hipGetErrorString(he);
+        pt_destroy(c);
+        return fail(nullptr, PT_ERR_HIP, m);
+    };
+    if ((e = hipSetDevice(p.device)) != hipSuccess) return bail("hipSetDevice", e);
+    if ((e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess)
+        return bail("hipStreamCreate", e);
+    c->stream = c->own_stream;
+    const size_t cbytes = npix(c) * 3 * sizeof(float);
+    if ((e = hipMalloc((void **)&c->d_canvas, cbytes)) != hipSuccess) return bail("hipMalloc(canvas)", e);
+    if ((e = hipMalloc((void **)&c->d_segments, sizeof(unsigned long long))) != hipSuccess)
+        return bail("hipMalloc(segments)", e);
+    if ((e = hipMemsetAsync(c->d_canvas, 0, cbytes, c->stream)) != hipSuccess) return bail("hipMemset", e);
+    if ((e = hipMemsetAsync(c->d_segments, 0, sizeof(unsigned long long), c->stream)) != hipSuccess)
+        return bail("hipMemset", e);
+    if ((e = hipEventCreate(&c->ev0)) != hipSuccess) return bail("hipEventCreate", e);
+    if ((e = hipEventCreate(&c->ev1)) != hipSuccess) return bail("hipEventCreate", e);
+    if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return bail("hipStreamSynchronize", e);
+    *out = c;
+    return PT_OK;
+}
+
+void pt_destroy(pt_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->p.device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->d_canvas) (void)hipFree(c->d_canvas);
+    if (c->d_segments) (void)hipFree(c->d_segments);
+    if (c->d_geom) (void)hipFree(c->d_geom);
+    if (c->d_mat) (void)hipFree(c->d_mat);
+    if (c->d_prim) (void)hipFree(c->d_prim);
+    if (c->d_rgb) (void)hipFree(c->d_rgb);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+int pt_scene_upload(pt_ctx *c, const pt_object *objs, int32_t n)
+{
+    if (int s = check_ctx(c)) return s;
+    if (!objs) return fail(c, PT_ERR_INVALID, "pt_scene_upload: null objects");
+    if (n < 1 || n > MAX_OBJECTS) return fail(c, PT_ERR_LIMIT, "pt_scene_upload: need 1 <= n <= 65536");
+    for (int k = 0; k < n; ++k)
+        if (objs[k].kind != PT_INFINITE_PLANE && objs[k].kind != PT_DISK)
+            return fail(c, PT_ERR_INVALID, "pt_scene_upload: unknown Form kind");
+
+    std::vector<float4> geom((size_t)n * 3), mat((size_t)n * 4);
+    std::vector<double> prim((size_t)n * PRIM_DOUBLES);
+    bool spec = false;
+    for (int k = 0; k < n; ++k) {
+        flatten_object(objs[k], &geom[(size_t)k * 3], &mat[(size_t)k * 4], &prim[(size_t)k * PRIM_DOUBLES]);
+        // only a non-emissive reflective object ever scatters specularly (src/Lib.hs:74-78)
+        spec = spec || (objs[k].reflective && !(objs[k].emittance > 0.0));
+    }
+    PT_HIP(c, hipStreamSynchronize(c->stream));
+    if (c->d_geom) { (void)hipFree(c->d_geom); c->d_geom = nullptr; }
+    if (c->d_mat) { (void)hipFree(c->d_mat); c->d_mat = nullptr; }
+    if (c->d_prim) { (void)hipFree(c->d_prim); c->d_prim = nullptr; }
+    c->n_obj = 0;
+    PT_HIP(c, hipMalloc((void **)&c->d_geom, geom.size() * sizeof(float4)));
+    PT_HIP(c, hipMalloc((void **)&c->d_mat, mat.size() * sizeof(float4)));
+    PT_HIP(c, hipMalloc((void **)&c->d_prim, prim.size() * sizeof(double)));
+    PT_HIP(c, hipMemcpy(c->d_geom, geom.data(), geom.size() * sizeof(float4), hipMemcpyHostToDevice));
+    PT_HIP(c, hipMemcpy(c->d_mat, mat.data(), mat.size() * sizeof(float4), hipMemcpyHostToDevice));
+    PT_HIP(c, hipMemcpy(c->d_prim, prim.data(), prim.size() * sizeof(double), hipMemcpyHostToDevice));
+    std::memset(&c->sg, 0, sizeof c->sg);
+    if (n <= MAX_STATIC_OBJECTS)
+        for (int k = 0; k < n; ++k)
+            for (int f = 0; f < 3; ++f) c->sg.g[k][f] = geom[(size_t)k * 3 + f];
+    c->n_obj = n;
+    c->has_specular = spec;
+    return PT_OK;
+}
+
+int pt_trace(pt_ctx *c, int32_t iters)
+{
+    if (int s = check_ctx(c)) return s;
+    if (c->n_obj < 1) return fail(c, PT_ERR_NO_SCENE, "pt_trace: no scene uploaded");
+    if (iters < 0) return fail(c, PT_ERR_INVALID, "pt_trace: iters < 0");
+    const int64_t last_global =
+        (int64_t)c->p.sample_offset + (c->samples_done + iters) * (int64_t)c->p.sample_stride;
+    if (last_global > MAX_GLOBAL_SAMPLES)
+        return fail(c, PT_ERR_LIMIT, "pt_trace: global sample index would exceed 2^26");
+
+    const bool reuse = !(c->p.flags & PT_FLAG_NO_PRIMARY_REUSE);
+    if (c->timing) PT_HIP(c, hipEventRecord(c->ev0, c->stream));
+    int launches = 0;
+    int32_t left = iters;
+    while (left > 0) {
+        const int32_t n = left < MAX_SAMPLES_PER_LAUNCH ? left : MAX_SAMPLES_PER_LAUNCH;
+        TraceArgs a{};
+        a.canvas = c->d_canvas; a.segments = c->d_segments;
+        a.geom = c->d_geom; a.mat = c->d_mat; a.prim = c->d_prim;
+        a.camera_depth = c->p.camera_depth;
+        a.n_obj = c->n_obj; a.height = c->p.height; a.width = c->p.width;
+        a.max_bounces = c->p.max_bounces; a.seed = c->p.seed;
+        a.sample_begin = (uint32_t)(c->p.sample_offset + c->samples_done * c->p.sample_stride);
+        a.sample_stride = (uint32_t)c->p.sample_stride;
+        a.n_samples = n;
+        PT_HIP(c, launch_trace(a, c->sg, reuse, c->has_specular, c->stream));
+        c->samples_done += n;
+        left -= n;
+        ++launches;
+    }
+    if (c->timing) {
+        PT_HIP(c, hipEventRecord(c->ev1, c->stream));
+        c->last_launches = launches;
+        c->have_timing = true;
+    }
+    return PT_OK;
+}
+
+int pt_reset(pt_ctx *c)
+{
+    if (int s = check_ctx(c)) return s;
+    PT_HIP(c, hipMemsetAsync(c->d_canvas, 0, npix(c) * 3 * sizeof(float), c->stream));
+    PT_HIP(c, hipMemsetAsync(c->d_segments, 0, sizeof(unsigned long long), c->stream));
+    c->samples_done = 0;
+    return PT_OK;
+}
+
+int pt_read_sum_f32(pt_ctx *c, float *out)
+{
+    if (int s = check_ctx(c)) return s;
+    if (!out) return fail(c, PT_ERR_INVALID, "pt_read_sum_f32: null output");
+    PT_HIP(c, hipMemcpyAsync(out, c->d_canvas, npix(c) * 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    PT_HIP(c, hipStreamSynchronize(c->stream));
+    return PT_OK;
+}
+
+int pt_read_sum(pt_ctx *c, double *out)
+{
+    if (int s = check_ctx(c)) return s;
+    if (!out) return fail(c, PT_ERR_INVALID, "pt_read_sum: null output");
+    std::vector<float> tmp(npix(c) * 3);
+    if (int s = pt_read_sum_f32(c, tmp.data())) return s;
+    for (size_t k = 0; k < tmp.size(); ++k) out[k] = (double)tmp[k];
+    return PT_OK;
+}
+
+int pt_rgb8_device(pt_ctx *c, void *d_out, int32_t mode, int64_t samples_override)
+{
+    if (int s = check_ctx(c)) return s;
+    if (!d_out) return fail(c, PT_ERR_INVALID, "pt_rgb8_device: null output");
+    if (mode < PT_RGB8_REFERENCE || mode > PT_RGB8_MEAN_GAMMA)
+        return fail(c, PT_ERR_INVALID, "pt_rgb8_device: unknown mode");
+    const int64_t ns = samples_override > 0 ? samples_override : c->samples_done;
+    const double inv = ns > 0 ? 1.0 / (double)ns : 0.0;
+    PT_HIP(c, launch_rgb8(c->d_canvas, (uint8_t *)d_out, c->p.height, c->p.width, mode, inv, c->stream));
+    return PT_OK;
+}
+
+int pt_read_rgb8(pt_ctx *c, uint8_t *out, int32_t mode)
+{
+    if (int s = check_ctx(c)) return s;
+    if (!out) return fail(c, PT_ERR_INVALID, "pt_read_rgb8: null output");
+    const size_t bytes = npix(c) * 3;
+    if (!c->d_rgb) PT_HIP(c, hipMalloc((void **)&c->d_rgb, bytes));
+    if (int s = pt_rgb8_device(c, c->d_rgb, mode, 0)) return s;
+    PT_HIP(c, hipMemcpyAsync(out, c->d_rgb, bytes, hipMemcpyDeviceToHost, c->stream));
+    PT_HIP(c, hipStreamSynchronize(c->stream));
+    return PT_OK;
+}
+
+int pt_primary_hits(pt_ctx *c, int32_t *idx, double *t, double *normal)
+{
+    if (int s = check_ctx(c)) return s;
+    if (c->n_obj < 1) return fail(c, PT_ERR_NO_SCENE, "pt_primary_hits: no scene uploaded");
+    const size_t n = npix(c);
+    int32_t *d_idx = nullptr; double *d_t = nullptr, *d_n = nullptr;
+    int rc = PT_OK;
+    hipError_t e = hipSuccess;
+    do {
+        if (idx && (e = hipMalloc((void **)&d_idx, n * sizeof(int32_t))) != hipSuccess) break;
+        if (t && (e = hipMalloc((void **)&d_t, n * sizeof(double))) != hipSuccess) break;
+        if (normal && (e = hipMalloc((void **)&d_n, n * 3 * sizeof(double))) != hipSuccess) break;
+        if ((e = launch_primary(c->d_prim, c->n_obj, c->p.height, c->p.width, c->p.camera_depth, d_idx, d_t,
+                                d_n, c->stream)) != hipSuccess) break;
+        if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) break;
+        if (idx && (e = hipMemcpy(idx, d_idx, n * sizeof(int32_t), hipMemcpyDeviceToHost)) != hipSuccess) break;
+        if (t && (e = hipMemcpy(t, d_t, n * sizeof(double), hipMemcpyDeviceToHost)) != hipSuccess) break;
+        if (normal && (e = hipMemcpy(normal, d_n, n * 3 * sizeof(double), hipMemcpyDeviceToHost)) != hipSuccess) break;
+    } while (0);
+    if (e != hipSuccess) rc = fail(c, PT_ERR_HIP, std::string("pt_primary_hits: ") + hipGetErrorString(e));
+    if (d_idx) (void)hipFree(d_idx);
+    if (d_t) (void)hipFree(d_t);
+    if (d_n) (void)hipFree(d_n);
+    return rc;
+}
+
+int pt_segments(pt_ctx *c, uint64_t *out)
+{
+    if (int s = check_ctx(c)) return s;
+    if (!out) return fail(c, PT_ERR_INVALID, "pt_segments: null output");
+    unsigned long long v = 0;
+    PT_HIP(c, hipMemcpyAsync(&v, c->d_segments, sizeof v, hipMemcpyDeviceToHost, c->stream));
+    PT_HIP(c, hipStreamSynchronize(c->stream));
+    *out = (uint64_t)v;
+    return PT_OK;
+}
+
+int pt_samples_done(pt_ctx *c, int64_t *out)
+{
+    if (!c || !out) return fail(c, PT_ERR_INVALID, "pt_samples_done: null argument");
+    *out = c->samples_done;
+    return PT_OK;
+}
+
+int pt_canvas_device_ptr(pt_ctx *c, void **dptr, size_t *bytes)
+{
+    if (!c || !dptr) return fail(c, PT_ERR_INVALID, "pt_canvas_device_ptr: null argument");
+    *dptr = c->d_canvas;
+    if (bytes) *bytes = npix(c) * 3 * sizeof(float);
+    return PT_OK;
+}
+
+int pt_set_stream(pt_ctx *c, void *hip_stream)
+{
+    if (int s = check_ctx(c)) return s;
+    PT_HIP(c, hipStreamSynchronize(c->stream));
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return PT_OK;
+}
+
+int pt_synchronize(pt_ctx *c)
+{
+    if (int s = check_ctx(c)) return s;
+    PT_HIP(c, hipStreamSynchronize(c->stream));
+    return PT_OK;
+}
+
+int pt_write_sum_f32(pt_ctx *c, const float *in, int64_t samples_done)
+{
+    if (int s = check_ctx(c)) return s;
+    if (!in || samples_done < 0) return fail(c, PT_ERR_INVALID, "pt_write_sum_f32: bad argument");
+    PT_HIP(c, hipMemcpyAsync(c->d_canvas, in, npix(c) * 3 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    PT_HIP(c, hipStreamSynchronize(c->stream));
+    c->samples_done = samples_done;
+    return PT_OK;
+}
+
+// ---- device-function parity hooks -------------------------------------------
+int pt_dev_diffuse(pt_ctx *c, int32_t n, const float *normal, const float *u, float *out)
+{
+    if (int s = check_ctx(c)) return s;
+    if (n < 1 || !normal || !u || !out) return fail(c, PT_ERR_INVALID, "pt_dev_diffuse: bad argument");
+    std::vector<float4> mat((size_t)n * 4);
+    float4 g[3]; double prim[PRIM_DOUBLES];
+    for (int k = 0; k < n; ++k) {
+        pt_object ob{};
+        ob.kind = PT_INFINITE_PLANE;
+        for (int q = 0; q < 3; ++q) ob.normal[q] = (double)normal[3 * k + q];
+        flatten_object(ob, g, &mat[(size_t)k * 4], prim);
+    }
+    DevBuf<float4> dm; DevBuf<float> du, dout;
+    PT_HIP(c, dm.alloc(mat.size())); PT_HIP(c, du.alloc((size_t)n * 2)); PT_HIP(c, dout.alloc((size_t)n * 3));
+    PT_HIP(c, dm.up(mat.data(), mat.size())); PT_HIP(c, du.up(u, (size_t)n * 2));
+    PT_HIP(c, launch_dev_diffuse(n, dm.p, du.p, dout.p, c->stream));
+    PT_HIP(c, hipStreamSynchronize(c->stream));
+    PT_HIP(c, dout.down(out, (size_t)n * 3));
+    return PT_OK;
+}
+
+int pt_dev_specular(pt_ctx *c, int32_t n, const float *vector, const float *normal, const float *u,
+                    float noise, float *out)
+{
+    if (int s = check_ctx(c)) return s;
+    if (n < 1 || !vector || !normal || !u || !out) return fail(c, PT_ERR_INVALID, "pt_dev_specular: bad argument");
+    std::vector<float> nh((size_t)n * 3);
+    for (int k = 0; k < n; ++k) {
+        const d3 h = normalize_(d3{(double)normal[3 * k], (double)normal[3 * k + 1], (double)normal[3 * k + 2]});
+        nh[3 * k] = (float)h.x; nh[3 * k + 1] = (float)h.y; nh[3 * k + 2] = (float)h.z;
+    }
+    const float noise_rev = noise >= 0.0f ? noise / 360.0f : NOISE_REV;
+    DevBuf<float> dv, dn, du, dout;
+    PT_HIP(c, dv.alloc((size_t)n * 3)); PT_HIP(c, dn.alloc((size_t)n * 3));
+    PT_HIP(c, du.alloc((size_t)n * 2)); PT_HIP(c, dout.alloc((size_t)n * 3));
+    PT_HIP(c, dv.up(vector, (size_t)n * 3)); PT_HIP(c, dn.up(nh.data(), (size_t)n * 3));
+    PT_HIP(c, du.up(u, (size_t)n * 2));
+    PT_HIP(c, launch_dev_specular(n, dv.p, dn.p, du.p, noise_rev, dout.p, c->stream));
+    PT_HIP(c, hipStreamSynchronize(c->stream));
+    PT_HIP(c, dout.down(out, (size_t)n * 3));
+    return PT_OK;
+}
+
+int pt_dev_distance(pt_ctx *c, int32_t n, const pt_object *obj, const float *origin, const float *vector,
+                    float *t_out)
+{
+    if (int s = check_ctx(c)) return s;
+    if (n < 1 || !obj || !origin || !vector || !t_out) return fail(c, PT_ERR_INVALID, "pt_dev_distance: bad argument");
+    if (obj->kind != PT_INFINITE_PLANE && obj->kind != PT_DISK)
+        return fail(c, PT_ERR_INVALID, "pt_dev_distance: unknown Form kind");
+    float4 g[3], m[4]; double prim[PRIM_DOUBLES];
+    flatten_object(*obj, g, m, prim);
+    DevBuf<float4> dg; DevBuf<float> dorg, dv, dt;
+    PT_HIP(c, dg.alloc(3)); PT_HIP(c, dorg.alloc((size_t)n * 3)); PT_HIP(c, dv.alloc((size_t)n * 3));
+    PT_HIP(c, dt.alloc((size_t)n));
+    PT_HIP(c, dg.up(g, 3)); PT_HIP(c, dorg.up(origin, (size_t)n * 3)); PT_HIP(c, dv.up(vector, (size_t)n * 3));
+    PT_HIP(c, launch_dev_distance(n, dg.p, dorg.p, dv.p, dt.p, c->stream));
+    PT_HIP(c, hipStreamSynchronize(c->stream));
+    PT_HIP(c, dt.down(t_out, (size_t)n));
+    return PT_OK;
+}
+
+int pt_dev_philox(pt_ctx *c, int32_t n, const uint32_t *c0, const uint32_t *c1, uint32_t key, uint32_t *out)
+{
+    if (int s = check_ctx(c)) return s;
+    if (n < 1 || !c0 || !c1 || !out) return fail(c, PT_ERR_INVALID, "pt_dev_philox: bad argument");
+    DevBuf<uint32_t> d0, d1, dout;
+    PT_HIP(c, d0.alloc((size_t)n)); PT_HIP(c, d1.alloc((size_t)n)); PT_HIP(c, dout.alloc((size_t)n * 2));
+    PT_HIP(c, d0.up(c0, (size_t)n)); PT_HIP(c, d1.up(c1, (size_t)n));
+    PT_HIP(c, launch_dev_philox(n, d0.p, d1.p, key, dout.p, c->stream));
+    PT_HIP(c, hipStreamSynchronize(c->stream));
+    PT_HIP(c, dout.down(out, (size_t)n * 2));
+    return PT_OK;
+}
+
+int pt_set_timing(pt_ctx *c, int32_t enable)
+{
+    if (!c) return fail(nullptr, PT_ERR_INVALID, "pt_set_timing: null context");
+    c->timing = enable != 0;
+    c->have_timing = false;
+    return PT_OK;
+}
+
+int pt_last_trace_ms(pt_ctx *c, float *ms, int32_t *launches)
+{
+    if (int s = check_ctx(c)) return s;
+    if (!ms) return fail(c, PT_ERR_INVALID, "pt_last_trace_ms: null output");
+    if (!c->have_timing) return fail(c, PT_ERR_INVALID, "pt_last_trace_ms: no timed pt_trace yet");
+    PT_HIP(c, hipEventSynchronize(c->ev1));
+    PT_HIP(c, hipEventElapsedTime(ms, c->ev0, c->ev1));
+    if (launches) *launches = c->last_launches;
+    return PT_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,212 @@
+// pt_device.hpp -- device-side maths of the radiance loop for gfx950 (wave64).
+//
+// fp32 VALU restatement of the reference's per-segment work, designed for the
+// CDNA4 issue model rather than translated from the Haskell:
+//   * Triple.hs vector algebra is inlined scalar fp32 (src/Triple.hs:47-69);
+//   * ray/plane/disk intersection uses per-object constants folded at upload
+//     (src/Object.hs:156-177);
+//   * the trig-of-inverse-trig chain of rotateRel (src/Util.hs:114-145) is
+//     replaced by its algebraic form: for a diffuse bounce the whole rotation
+//     is a per-object 3x3 matrix, for a specular bounce it is built from the
+//     mirror direction's components with one rsqrt;
+//   * random draws come from Philox2x32-10 keyed by (pixel, sample, bounce).
+// The per-pixel primary segment alone is fp64 and follows the reference's
+// operation order, so primary-hit indices are bit-exact (src/Lib.hs:41-51,
+// :81-98).
+// File:line citations are relative to the reference repository root.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pt {
+
+// ---- device scene layout --------------------------------------------------
+// Geometry record, 12 floats (3 x float4), read with a wave-uniform index:
+//   g0 = (n_raw.x, n_raw.y, n_raw.z, A)        A  = point . n_raw
+//   g1 = (n_hat.x, n_hat.y, n_hat.z, r2)       r2 = radius^2, +inf for a plane
+//   g2 = (c.x, c.y, c.z, 0)                    disk centre
+// so that  t = (A - o.n_raw) / (v.n_hat)  ==  ((p-o).n) / (v.normalize n)
+// (src/Object.hs:176-177, raw normal above and unit normal below kept).
+constexpr int GEOM_FLOATS = 12;
+// Material record, 16 floats (4 x float4), read with a per-lane index:
+//   m0 = (color.r, color.g, color.b, e)   e > 0: emittance (light)
+//                                         e = 0: diffuse, e = -1: reflective
+//   m1 = (M00, M01, M02, n_hat.x)         M = |n| * Rz(phi') * Ry(theta'),
+//   m2 = (M10, M11, M12, n_hat.y)         (theta', phi') = toSphericalCoords n
+//   m3 = (M20, M21, M22, n_hat.z)         (src/Util.hs:114-145)
+constexpr int MAT_FLOATS = 16;
+// fp64 record for the primary pass, 11 doubles:
+//   point[3], n_raw[3], n_hat[3] (normalize n, src/Triple.hs:66-69), radius, kind
+constexpr int PRIM_DOUBLES = 11;
+
+constexpr int MAX_STATIC_OBJECTS = 8;
+
+struct f3 { float x, y, z; };
+
+__device__ __forceinline__ f3 mk3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ float dot3(f3 a, f3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
+__device__ __forceinline__ f3 fma3(float s, f3 a, f3 b) { return mk3(fmaf(s, a.x, b.x), fmaf(s, a.y, b.y), fmaf(s, a.z, b.z)); }
+
+// ---- Philox2x32-10 ----------------------------------------------------------
+// Salmon, Moraes, Dror, Shaw, SC'11.  One call = the two uniforms one bounce
+// needs (randomRangeList gen [(0,a),(0,380)], src/Lib.hs:127,132).  The key
+// schedule is wave-uniform, so the ten round keys live in SGPRs.
+__device__ __forceinline__ void philox2x32_10(uint32_t c0, uint32_t c1, uint32_t key,
+                                              uint32_t &o0, uint32_t &o1)
+{
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t prod = (uint64_t)0xD256D193u * (uint64_t)c0;
+        const uint32_t hi = (uint32_t)(prod >> 32), lo = (uint32_t)prod;
+        c0 = hi ^ (key + (uint32_t)r * 0x9E3779B9u) ^ c1;
+        c1 = lo;
+    }
+    o0 = c0; o1 = c1;
+}
+
+// 24-bit uniform in [0,1): exactly representable in fp32 and fp64, so the
+// device and the oracle's Philox mode see the same number.
+__device__ __forceinline__ float u24(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }
+
+// sin/cos of an angle given in REVOLUTIONS (v_sin_f32 / v_cos_f32 take the
+// argument pre-divided by 2*pi; |x| <= 256).
+__device__ __forceinline__ float sin_rev(float x) { return __builtin_amdgcn_sinf(x); }
+__device__ __forceinline__ float cos_rev(float x) { return __builtin_amdgcn_cosf(x); }
+
+// fromSphericalCoords (src/Util.hs:124-129) with theta, phi in revolutions.
+__device__ __forceinline__ f3 local_dir(float theta_rev, float phi_rev)
+{
+    const float st = sin_rev(theta_rev), ct = cos_rev(theta_rev);
+    const float sp = sin_rev(phi_rev),   cp = cos_rev(phi_rev);
+    return mk3(cp * st, sp * st, ct);
+}
+
+constexpr float PHI_REV   = 380.0f / 360.0f;   // phi ~ U(0, 380) degrees (sic), src/Lib.hs:127,132
+constexpr float THETA_DIFFUSE_REV = 0.25f;      // theta ~ U(0, 90) degrees, src/Lib.hs:132
+constexpr float NOISE_REV = 40.0f / 360.0f;    // specular noise 40 degrees, src/Lib.hs:110
+
+// diffuse (src/Lib.hs:129-132): rotateRel theta phi normal, with the rotation
+// about the (per-object constant) normal folded into M at upload.
+__device__ __forceinline__ f3 scatter_diffuse(float4 m1, float4 m2, float4 m3, float u1, float u2)
+{
+    const f3 l = local_dir(THETA_DIFFUSE_REV * u1, PHI_REV * u2);
+    return mk3(fmaf(m1.z, l.z, fmaf(m1.y, l.y, m1.x * l.x)),
+               fmaf(m2.z, l.z, fmaf(m2.y, l.y, m2.x * l.x)),
+               fmaf(m3.z, l.z, fmaf(m3.y, l.y, m3.x * l.x)));
+}
+
+// asin(x)/(2*pi) for x in [0,1], in revolutions.  Abramowitz-Stegun 4.4.46
+// form acos(x) = sqrt(1-x) * P7(x), |err| < 2e-8 rad before fp32 rounding.
+__device__ __forceinline__ float asin_rev01(float x)
+{
+    float p = -0.0012624911f;
+    p = fmaf(p, x,  0.0066700901f);
+    p = fmaf(p, x, -0.0170881256f);
+    p = fmaf(p, x,  0.0308918810f);
+    p = fmaf(p, x, -0.0501743046f);
+    p = fmaf(p, x,  0.0889789874f);
+    p = fmaf(p, x, -0.2145988016f);
+    p = fmaf(p, x,  1.5707963050f);
+    const float acos_x = __builtin_amdgcn_sqrtf(fmaxf(1.0f - x, 0.0f)) * p;
+    return (1.5707963268f - acos_x) * 0.15915494309f;
+}
+
+// specular (src/Lib.hs:115-127) + rotateRel about the mirror direction
+// (src/Util.hs:140-145).  n_hat = normalize normal.  Direction length is
+// preserved (the reference rescales by norm2 vector').
+__device__ __forceinline__ f3 scatter_specular(f3 v, f3 nh, float u1, float u2, float noise_rev)
+{
+    const float dvn = dot3(v, nh);
+    const f3 vp = fma3(-2.0f * dvn, nh, v);                 // vector + (-2) * projection
+    const float len2 = dot3(v, v);
+    const float len  = __builtin_amdgcn_sqrtf(len2);
+    const float inv  = __builtin_amdgcn_rcpf(fmaxf(len, 1e-6f));   // normalize floors the norm at 1e-6
+    // angleWithSurface = 90 - acos |n_hat . v_hat|  ==  asin |n_hat . v_hat|
+    const float c = fminf(fabsf(dvn) * inv, 1.0f);
+    const float max_theta = fminf(asin_rev01(c), noise_rev);
+    const f3 l = local_dir(max_theta * u1, PHI_REV * u2);
+    // toSphericalCoords vector' (src/Util.hs:114-122) in algebraic form:
+    //   cos th' = a.z, sin th' = rho, cos ph' = a.x/rho, sin ph' = a.y/rho,
+    // a = normalize vector', rho = sqrt(a.x^2 + a.y^2).
+    const float lenp = __builtin_amdgcn_sqrtf(dot3(vp, vp));
+    const float invp = __builtin_amdgcn_rcpf(fmaxf(lenp, 1e-6f));
+    const f3 a = mk3(vp.x * invp, vp.y * invp, vp.z * invp);
+    const float rho2 = fmaf(a.y, a.y, a.x * a.x);
+    float ct, st, cp, sp;
+    if (rho2 > 0.0f) {
+        const float irho = __builtin_amdgcn_rsqf(rho2);
+        ct = a.z; st = rho2 * irho;
+        cp = a.x * irho; sp = a.y * irho;
+        // arctan2 takes x = -0.0 through its x >= 0 branch with y/x = -+Inf
+        // (src/Util.hs:106-112): phi' lands on the opposite side.
+        if (a.x == 0.0f && __builtin_signbit(a.x)) sp = -sp;
+    } else {
+        // x = y = 0 guards (src/Util.hs:116-117): (0,0) or (180,0)
+        ct = (a.z >= 0.0f) ? 1.0f : -1.0f; st = 0.0f; cp = 1.0f; sp = 0.0f;
+    }
+    // rotateAbs local theta' phi' (src/Util.hs:131-138)
+    const float x = fmaf(st * cp, l.z, fmaf(-sp, l.y, (ct * cp) * l.x));
+    const float y = fmaf(sp * st, l.z, fmaf( cp, l.y, (sp * ct) * l.x));
+    const float z = fmaf(ct, l.z, -st * l.x);
+    return mk3(x * lenp, y * lenp, z * lenp);
+}
+
+// distanceFrom (src/Object.hs:156-177) for one object against one ray.
+// Returns t, or NaN where the reference returns Nothing.
+__device__ __forceinline__ float distance_from(float4 g0, float4 g1, float4 g2, f3 o, f3 v)
+{
+    const float num = fmaf(-o.z, g0.z, fmaf(-o.y, g0.y, fmaf(-o.x, g0.x, g0.w)));
+    const float den = fmaf(v.z, g1.z, fmaf(v.y, g1.y, v.x * g1.x));
+    const float t = num * __builtin_amdgcn_rcpf(den);
+    bool ok = (t > 0.0f) && (t < __builtin_inff());          // guard, src/Object.hs:159
+    if (g1.w != __builtin_inff()) {                           // Disk, src/Object.hs:165-171
+        const f3 d = mk3(fmaf(t, v.x, o.x) - g2.x, fmaf(t, v.y, o.y) - g2.y, fmaf(t, v.z, o.z) - g2.z);
+        ok = ok && (dot3(d, d) < g1.w);
+    }
+    return ok ? t : __builtin_nanf("");
+}
+
+// ---- fp64 primary segment --------------------------------------------------
+// rayFromCamToPixel + closestObjectTo for the un-jittered primary ray
+// (src/Lib.hs:41-51, :81-98), in the reference's operation order with
+// contraction off.  prim = PRIM_DOUBLES doubles per object.
+struct PrimaryHit { int idx; double t; double dx, dy, dz; };
+
+__device__ inline PrimaryHit primary_hit_f64(const double *__restrict__ prim, int n,
+                                             int H, int W, double camera_depth, int i, int j)
+{
+#pragma clang fp contract(off)
+    PrimaryHit h;
+    const double ip = (double)H / 2.0 - (double)i;
+    const double jp = (double)j - (double)W / 2.0;
+    const double nrm = sqrt(ip * ip + jp * jp + camera_depth * camera_depth);
+    const double floor_ = 1e-6;
+    const double norm = (floor_ <= nrm) ? nrm : floor_;
+    h.dx = ip / norm; h.dy = jp / norm; h.dz = camera_depth / norm;
+    h.idx = -1; h.t = 0.0;
+    for (int k = 0; k < n; ++k) {
+        const double *p = prim + (size_t)k * PRIM_DOUBLES;
+        // (point - origin) with origin = 0, then `dot` as a left fold from 0
+        double num = 0.0;
+        num = num + (p[0] - 0.0) * p[3];
+        num = num + (p[1] - 0.0) * p[4];
+        num = num + (p[2] - 0.0) * p[5];
+        double den = 0.0;
+        den = den + h.dx * p[6];
+        den = den + h.dy * p[7];
+        den = den + h.dz * p[8];
+        const double t = num / den;
+        bool ok = (0.0 < t) && (t < (double)__builtin_inff());
+        if (ok && p[10] != 0.0) {                             // Disk
+            const double px = 0.0 + t * h.dx - p[0];
+            const double py = 0.0 + t * h.dy - p[1];
+            const double pz = 0.0 + t * h.dz - p[2];
+            ok = sqrt(px * px + py * py + pz * pz) < p[9];
+        }
+        if (ok && (h.idx < 0 || t < h.t)) { h.idx = k; h.t = t; }
+    }
+    return h;
+}
+
+} // namespace pt

@@ -1,0 +1,51 @@
+// pt_internal.hpp -- launch-parameter structs shared by the kernels and the
+// C ABI implementation.  Not part of the public interface (include/pt.h is).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "pt_device.hpp"
+
+namespace pt {
+
+// Geometry of a small scene passed BY VALUE in the kernel-argument segment:
+// the closest-hit loop indexes objects with a wave-uniform index, so hipcc
+// fetches these with s_load into SGPRs and the VALU reads them as scalar
+// operands -- no VGPRs and no LDS bandwidth spent on the object list.
+struct StaticGeom {
+    float4 g[MAX_STATIC_OBJECTS][3];
+};
+
+struct TraceArgs {
+    float              *canvas;        // H*W*3 fp32 radiance sums, (i*W+j)*3+k
+    unsigned long long *segments;      // closest-hit searches executed
+    const float4       *geom;          // n_obj * 3 float4   (dynamic path)
+    const float4       *mat;           // n_obj * 4 float4
+    const double       *prim;          // n_obj * PRIM_DOUBLES
+    double   camera_depth;
+    int      n_obj;
+    int      height, width;
+    int      max_bounces;
+    uint32_t seed;
+    uint32_t sample_begin;             // global index of this launch's first sample
+    uint32_t sample_stride;
+    int      n_samples;                // samples per pixel in this launch
+};
+
+// Launchers (pt_kernels.hip).  All return the hipError_t of the launch.
+hipError_t launch_trace(const TraceArgs &a, const StaticGeom &sg, bool reuse_primary,
+                        bool has_specular, hipStream_t s);
+hipError_t launch_primary(const double *prim, int n_obj, int H, int W, double camera_depth,
+                          int32_t *idx, double *t, double *normal, hipStream_t s);
+hipError_t launch_rgb8(const float *canvas, uint8_t *rgb, int H, int W, int mode,
+                       double inv_samples, hipStream_t s);
+hipError_t launch_dev_diffuse(int n, const float4 *mat1, const float *u, float *out, hipStream_t s);
+hipError_t launch_dev_specular(int n, const float *v, const float *nrm, const float *u,
+                               float noise_rev, float *out, hipStream_t s);
+hipError_t launch_dev_distance(int n, const float4 *geom1, const float *o, const float *v,
+                               float *t, hipStream_t s);
+hipError_t launch_dev_philox(int n, const uint32_t *c0, const uint32_t *c1, uint32_t key,
+                             uint32_t *out, hipStream_t s);
+
+} // namespace pt

@@ -1,0 +1,369 @@
+// pt_kernels.hip -- gfx950 kernels of the radiance loop.
+//
+//   trace_kernel   : Lib.traceCanvas / terminalColor / closestObjectTo /
+//                    bounceRay (src/Lib.hs:58-132) for n samples per pixel.
+//   primary_kernel : fp64 primary segment, the geometry parity hook.
+//   rgb8_kernel    : Conversion.repa3ToImage + listToPixelRGB8
+//                    (src/Conversion.hs:17-28), transposing through LDS.
+//   dev_* kernels  : device-function parity hooks.
+//
+// Execution model of trace_kernel (one lane = one pixel, a wave = 64 adjacent
+// pixels of a canvas row):
+//   every lane runs a SEGMENT state machine -- one closest-hit search plus one
+//   scatter per loop trip -- and a lane whose path ends (miss, light, depth
+//   cap) starts its pixel's next sample in the same trip.  All 64 lanes
+//   therefore execute the same instruction stream on every trip no matter how
+//   long their individual paths are; the only idle lanes are those that have
+//   finished their whole sample quota (the tail).  Path depth divergence,
+//   which would otherwise leave a wave running at the pace of its longest
+//   path, never reaches the exec mask.
+//   The object list is indexed wave-uniformly, so for small scenes it rides
+//   in SGPRs (kernel-argument segment); materials are per-lane gathers from
+//   an LDS copy staged once per workgroup.
+#include "pt_internal.hpp"
+
+namespace pt {
+
+// ---------------------------------------------------------------------------
+// closest-hit search (closestObjectTo, src/Lib.hs:81-98)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void test_object(float4 g0, float4 g1, float4 g2, int k, f3 o, f3 v,
+                                            int last, int &best, float &best_t)
+{
+    const float num = fmaf(-o.z, g0.z, fmaf(-o.y, g0.y, fmaf(-o.x, g0.x, g0.w)));
+    const float den = fmaf(v.z, g1.z, fmaf(v.y, g1.y, v.x * g1.x));
+    const float t = num * __builtin_amdgcn_rcpf(den);
+    // 0 < t < Inf (src/Object.hs:159), not the last-struck object
+    // (src/Lib.hs:86-90), strictly closer than the best so far: an equal t
+    // keeps the earlier object, as Data.Vector.minimumBy does.
+    bool ok = (t > 0.0f) && (t < best_t) && (k != last);
+    if (g1.w != __builtin_inff()) {          // wave-uniform: Disk (src/Object.hs:165-171)
+        const float dx = fmaf(t, v.x, o.x) - g2.x;
+        const float dy = fmaf(t, v.y, o.y) - g2.y;
+        const float dz = fmaf(t, v.z, o.z) - g2.z;
+        ok = ok && (fmaf(dz, dz, fmaf(dy, dy, dx * dx)) < g1.w);
+    }
+    if (ok) { best = k; best_t = t; }
+}
+
+template <int NS>
+__device__ __forceinline__ void closest(const TraceArgs &a, const StaticGeom &sg, f3 o, f3 v,
+                                        int last, int &best, float &best_t)
+{
+    best = -1; best_t = __builtin_inff();
+    if constexpr (NS > 0) {
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            if (k < a.n_obj)
+                test_object(sg.g[k][0], sg.g[k][1], sg.g[k][2], k, o, v, last, best, best_t);
+        }
+    } else {
+        const float4 *__restrict__ g = a.geom;
+        for (int k = 0; k < a.n_obj; ++k)
+            test_object(g[3 * k + 0], g[3 * k + 1], g[3 * k + 2], k, o, v, last, best, best_t);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// trace kernel
+// ---------------------------------------------------------------------------
+constexpr int TRACE_BLOCK = 256;
+
+template <int NS, bool REUSE, bool SPEC>
+__global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(TraceArgs a, StaticGeom sg)
+{
+    // Materials: LDS copy for small scenes (per-lane gather, <= 4 distinct
+    // 64-B records land on distinct banks), global/L2 gather otherwise.
+    __shared__ float4 s_mat[(NS > 0 ? NS : 1) * 4];
+    if constexpr (NS > 0) {
+        if ((int)threadIdx.x < a.n_obj * 4) s_mat[threadIdx.x] = a.mat[threadIdx.x];
+        __syncthreads();
+    }
+    auto mat = [&](int k, int f) -> float4 {
+        if constexpr (NS > 0) return s_mat[k * 4 + f];
+        else                  return a.mat[k * 4 + f];
+    };
+
+    const int npix = a.height * a.width;
+    const int pixel = blockIdx.x * TRACE_BLOCK + threadIdx.x;
+    const bool in_canvas = pixel < npix;
+    const int pc = in_canvas ? pixel : 0;
+    const int pi = pc / a.width, pj = pc - pi * a.width;
+
+    unsigned long long segs = 0;
+    int n_my = in_canvas ? a.n_samples : 0;
+
+    // traceCanvas adds onto the running sum (src/Lib.hs:65); continuing the
+    // fp32 sum sample by sample makes k launches of 1 equal 1 launch of k.
+    f3 acc = mk3(0.f, 0.f, 0.f);
+    if (in_canvas) acc = mk3(a.canvas[3 * pc + 0], a.canvas[3 * pc + 1], a.canvas[3 * pc + 2]);
+
+    // Primary segment: no jitter, no randomness (src/Lib.hs:41-51), so it is
+    // computed once per pixel, in fp64, reference operation order.
+    const PrimaryHit ph = primary_hit_f64(a.prim, a.n_obj, a.height, a.width, a.camera_depth, pi, pj);
+    const f3 d0 = mk3((float)ph.dx, (float)ph.dy, (float)ph.dz);
+    const int B = a.max_bounces;
+
+    f3 P0 = mk3(0.f, 0.f, 0.f), color0 = mk3(1.f, 1.f, 1.f);
+    int idx0 = -1; float e0 = 0.f;
+    if constexpr (REUSE) {
+        if (in_canvas) segs += 1;
+        idx0 = ph.idx;
+        if (idx0 < 0) {
+            n_my = 0;                                    // every sample is black (src/Lib.hs:72)
+        } else {
+            const float4 m0 = mat(idx0, 0);
+            e0 = m0.w; color0 = mk3(m0.x, m0.y, m0.z);
+            P0 = mk3((float)(ph.t * ph.dx), (float)(ph.t * ph.dy), (float)(ph.t * ph.dz));
+            if (e0 > 0.f) {                              // primary ray sees a light (src/Lib.hs:74)
+                for (int s = 0; s < n_my; ++s) { acc.x += e0; acc.y += e0; acc.z += e0; }
+                n_my = 0;
+            } else if (B < 2) {
+                n_my = 0;                                // terminalColor 0 = black (src/Lib.hs:68)
+            }
+        }
+    }
+
+    // per-lane path state
+    f3 o = mk3(0.f, 0.f, 0.f), d = d0, thr = mk3(1.f, 1.f, 1.f);
+    int last = -1, b = 0, s = 0;
+    uint32_t gs = a.sample_begin;
+
+    auto scatter = [&](int idx, float e, f3 din, int bounce) -> f3 {
+        uint32_t r0, r1;
+        philox2x32_10((uint32_t)pc, (gs << 6) | (uint32_t)bounce, a.seed, r0, r1);
+        const float u1 = u24(r0), u2 = u24(r1);
+        const float4 m1 = mat(idx, 1), m2 = mat(idx, 2), m3 = mat(idx, 3);
+        if constexpr (SPEC) {
+            if (e < 0.f)                                   // _reflective (src/Lib.hs:110)
+                return scatter_specular(din, mk3(m1.w, m2.w, m3.w), u1, u2, NOISE_REV);
+        }
+        return scatter_diffuse(m1, m2, m3, u1, u2);        // src/Lib.hs:111
+    };
+
+    if constexpr (REUSE) {
+        if (n_my > 0) {
+            d = scatter(idx0, e0, d0, 0);
+            o = P0; last = idx0; thr = color0; b = 1;
+        }
+    }
+
+    while (s < n_my) {
+        int k; float t;
+        closest<NS>(a, sg, o, d, last, k, t);
+        segs += 1;
+        const bool hit = k >= 0;
+        const float4 m0 = mat(hit ? k : 0, 0);
+        const bool emissive = hit && (m0.w > 0.f);
+        // after this search b+1 have run; terminalColor 0 ends the path black
+        const bool terminal = !hit || emissive || (b + 1 >= B);
+        if (emissive) {                                    // emittance * pixel (src/Lib.hs:74)
+            acc.x = fmaf(m0.w, thr.x, acc.x);
+            acc.y = fmaf(m0.w, thr.y, acc.y);
+            acc.z = fmaf(m0.w, thr.z, acc.z);
+        }
+        if constexpr (REUSE) {
+            // a finished path restarts from the pixel's primary hit
+            if (terminal) { s += 1; gs += a.sample_stride; }
+            const int   idx = terminal ? idx0 : k;
+            const float e   = terminal ? e0 : m0.w;
+            const f3    din = terminal ? d0 : d;
+            const int   bn  = terminal ? 0 : b;
+            const f3 hp = mk3(terminal ? P0.x : fmaf(t, d.x, o.x),     // march (src/Object.hs:151-153)
+                              terminal ? P0.y : fmaf(t, d.y, o.y),
+                              terminal ? P0.z : fmaf(t, d.z, o.z));
+            thr = mk3(terminal ? color0.x : thr.x * m0.x,               // pixel * color (src/Lib.hs:79)
+                      terminal ? color0.y : thr.y * m0.y,
+                      terminal ? color0.z : thr.z * m0.z);
+            d = scatter(idx, e, din, bn);
+            o = hp; last = idx; b = bn + 1;
+        } else {
+            if (terminal) {
+                s += 1; gs += a.sample_stride;
+                o = mk3(0.f, 0.f, 0.f); d = d0; thr = mk3(1.f, 1.f, 1.f); last = -1; b = 0;
+            } else {
+                const f3 hp = fma3(t, d, o);
+                thr = mk3(thr.x * m0.x, thr.y * m0.y, thr.z * m0.z);
+                d = scatter(k, m0.w, d, b);
+                o = hp; last = k; b += 1;
+            }
+        }
+    }
+
+    if (in_canvas) {
+        a.canvas[3 * pc + 0] = acc.x; a.canvas[3 * pc + 1] = acc.y; a.canvas[3 * pc + 2] = acc.z;
+    }
+
+    // one 64-bit atomic per wave for the segment counter
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) segs += __shfl_down(segs, off, 64);
+    if ((threadIdx.x & 63) == 0 && segs) atomicAdd(a.segments, segs);
+}
+
+template <int NS>
+static hipError_t launch_trace_ns(const TraceArgs &a, const StaticGeom &sg, bool reuse, bool spec,
+                                  hipStream_t s)
+{
+    const int npix = a.height * a.width;
+    const dim3 grid((npix + TRACE_BLOCK - 1) / TRACE_BLOCK), block(TRACE_BLOCK);
+    if (reuse) {
+        if (spec) hipLaunchKernelGGL((trace_kernel<NS, true, true>), grid, block, 0, s, a, sg);
+        else      hipLaunchKernelGGL((trace_kernel<NS, true, false>), grid, block, 0, s, a, sg);
+    } else {
+        if (spec) hipLaunchKernelGGL((trace_kernel<NS, false, true>), grid, block, 0, s, a, sg);
+        else      hipLaunchKernelGGL((trace_kernel<NS, false, false>), grid, block, 0, s, a, sg);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_trace(const TraceArgs &a, const StaticGeom &sg, bool reuse, bool spec, hipStream_t s)
+{
+    if (a.n_obj <= MAX_STATIC_OBJECTS) return launch_trace_ns<MAX_STATIC_OBJECTS>(a, sg, reuse, spec, s);
+    return launch_trace_ns<0>(a, sg, reuse, spec, s);
+}
+
+// ---------------------------------------------------------------------------
+// primary hits (fp64), parity hook
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void primary_kernel(const double *__restrict__ prim, int n_obj, int H,
+                                                      int W, double camera_depth, int32_t *idx,
+                                                      double *t, double *normal)
+{
+    const int pixel = blockIdx.x * 256 + threadIdx.x;
+    if (pixel >= H * W) return;
+    const int i = pixel / W, j = pixel - i * W;
+    const PrimaryHit h = primary_hit_f64(prim, n_obj, H, W, camera_depth, i, j);
+    if (idx) idx[pixel] = h.idx;
+    if (t) t[pixel] = h.idx >= 0 ? h.t : 0.0;
+    if (normal) {
+        for (int c = 0; c < 3; ++c)
+            normal[3 * (size_t)pixel + c] = h.idx >= 0 ? prim[(size_t)h.idx * PRIM_DOUBLES + 3 + c] : 0.0;
+    }
+}
+
+hipError_t launch_primary(const double *prim, int n_obj, int H, int W, double camera_depth,
+                          int32_t *idx, double *t, double *normal, hipStream_t s)
+{
+    const int npix = H * W;
+    hipLaunchKernelGGL(primary_kernel, dim3((npix + 255) / 256), dim3(256), 0, s, prim, n_obj, H, W,
+                       camera_depth, idx, t, normal);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// RGB8 output (src/Conversion.hs:17-28)
+// ---------------------------------------------------------------------------
+// canvas (i*W + j)*3 + k  ->  rgb (j*H + i)*3 + k : a transpose of the pixel
+// grid.  A 64(i) x 64(j) tile is read along j (coalesced fp32), quantised, and
+// written along i (coalesced bytes) after a trip through LDS.
+constexpr int RGB_TILE = 64;
+
+__device__ __forceinline__ uint8_t quantise(float sum, int mode, double inv_samples)
+{
+    double x = (double)sum;
+    if (mode != 0) {
+        x = x * inv_samples;
+        x = x < 0.0 ? 0.0 : (x > 1.0 ? 1.0 : x);
+        if (mode == 2) x = pow(x, 1.0 / 2.2);
+    }
+    // round :: Double -> Word8 == half-even to Int, then wrap mod 256
+    const double r = rint(255.0 * x);
+    return (uint8_t)(unsigned long long)(long long)r;
+}
+
+__global__ __launch_bounds__(256) void rgb8_kernel(const float *__restrict__ canvas, uint8_t *__restrict__ rgb,
+                                                   int H, int W, int mode, double inv_samples)
+{
+    __shared__ uint8_t tile[RGB_TILE][RGB_TILE * 3 + 4];     // [jj][ii*3+k], padded
+    const int i0 = blockIdx.y * RGB_TILE, j0 = blockIdx.x * RGB_TILE;
+    const int tj = min(RGB_TILE, W - j0), ti = min(RGB_TILE, H - i0);
+    // read: row ii of the tile is tj*3 contiguous floats
+    for (int ii = threadIdx.x / 64; ii < ti; ii += 4) {
+        const float *row = canvas + ((size_t)(i0 + ii) * W + j0) * 3;
+        for (int e = threadIdx.x % 64; e < tj * 3; e += 64) {
+            const int jj = e / 3, k = e - jj * 3;
+            tile[jj][ii * 3 + k] = quantise(row[e], mode, inv_samples);
+        }
+    }
+    __syncthreads();
+    // write: row jj of the output tile is ti*3 contiguous bytes
+    for (int jj = threadIdx.x / 64; jj < tj; jj += 4) {
+        uint8_t *row = rgb + ((size_t)(j0 + jj) * H + i0) * 3;
+        for (int e = threadIdx.x % 64; e < ti * 3; e += 64) row[e] = tile[jj][e];
+    }
+}
+
+hipError_t launch_rgb8(const float *canvas, uint8_t *rgb, int H, int W, int mode, double inv_samples,
+                       hipStream_t s)
+{
+    const dim3 grid((W + RGB_TILE - 1) / RGB_TILE, (H + RGB_TILE - 1) / RGB_TILE);
+    hipLaunchKernelGGL(rgb8_kernel, grid, dim3(256), 0, s, canvas, rgb, H, W, mode, inv_samples);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// device-function parity hooks
+// ---------------------------------------------------------------------------
+__global__ void dev_diffuse_kernel(int n, const float4 *__restrict__ m, const float *__restrict__ u,
+                                   float *__restrict__ out)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const f3 r = scatter_diffuse(m[4 * k + 1], m[4 * k + 2], m[4 * k + 3], u[2 * k], u[2 * k + 1]);
+    out[3 * k] = r.x; out[3 * k + 1] = r.y; out[3 * k + 2] = r.z;
+}
+
+__global__ void dev_specular_kernel(int n, const float *__restrict__ v, const float *__restrict__ nh,
+                                    const float *__restrict__ u, float noise_rev, float *__restrict__ out)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const f3 r = scatter_specular(mk3(v[3 * k], v[3 * k + 1], v[3 * k + 2]),
+                                  mk3(nh[3 * k], nh[3 * k + 1], nh[3 * k + 2]), u[2 * k], u[2 * k + 1],
+                                  noise_rev);
+    out[3 * k] = r.x; out[3 * k + 1] = r.y; out[3 * k + 2] = r.z;
+}
+
+__global__ void dev_distance_kernel(int n, const float4 *__restrict__ g, const float *__restrict__ o,
+                                    const float *__restrict__ v, float *__restrict__ t)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    t[k] = distance_from(g[0], g[1], g[2], mk3(o[3 * k], o[3 * k + 1], o[3 * k + 2]),
+                         mk3(v[3 * k], v[3 * k + 1], v[3 * k + 2]));
+}
+
+__global__ void dev_philox_kernel(int n, const uint32_t *__restrict__ c0, const uint32_t *__restrict__ c1,
+                                  uint32_t key, uint32_t *__restrict__ out)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    uint32_t a, b;
+    philox2x32_10(c0[k], c1[k], key, a, b);
+    out[2 * k] = a; out[2 * k + 1] = b;
+}
+
+hipError_t launch_dev_diffuse(int n, const float4 *m, const float *u, float *out, hipStream_t s)
+{
+    hipLaunchKernelGGL(dev_diffuse_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, m, u, out);
+    return hipGetLastError();
+}
+hipError_t launch_dev_specular(int n, const float *v, const float *nh, const float *u, float noise_rev,
+                               float *out, hipStream_t s)
+{
+    hipLaunchKernelGGL(dev_specular_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, v, nh, u, noise_rev, out);
+    return hipGetLastError();
+}
+hipError_t launch_dev_distance(int n, const float4 *g, const float *o, const float *v, float *t, hipStream_t s)
+{
+    hipLaunchKernelGGL(dev_distance_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, g, o, v, t);
+    return hipGetLastError();
+}
+hipError_t launch_dev_philox(int n, const uint32_t *c0, const uint32_t *c1, uint32_t key, uint32_t *out,
+                             hipStream_t s)
+{
+    hipLaunchKernelGGL(dev_philox_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, c0, c1, key, out);
+    return hipGetLastError();
+}
+
+} // namespace pt

@@ -1,0 +1,174 @@
+"""Host side of the radiance loop: `Renderer` owns one libpt context (one GPU);
+`traces` and `repa3ToImage` keep the reference's names and meaning
+(src/Lib.hs:53-56, src/Conversion.hs:22-28)."""
+import ctypes as C
+from typing import Iterator, Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from ._lib import check, lib
+from .scene import Object, Params, objects as default_objects, to_c_array
+
+
+class Renderer:
+    """One pt_ctx: Params + an uploaded scene + the fp32 radiance-sum canvas in HBM."""
+
+    def __init__(self, params: Params, objs: Optional[Sequence[Object]] = None, *, seed: int = 0,
+                 device: int = 0, sample_offset: int = 0, sample_stride: int = 1, flags: int = 0):
+        self.params = params
+        p = _lib.pt_params(params.height, params.width, float(params.cameraDepth), params.maxBounces,
+                           seed, device, sample_offset, sample_stride, flags)
+        self._ctx = C.c_void_p()
+        check(lib.pt_create(C.byref(self._ctx), C.byref(p)))
+        self.shape = (params.height, params.width, 3)
+        if objs is None:
+            objs = default_objects
+        self.upload(objs)
+
+    # -- lifetime ---------------------------------------------------------
+    def close(self):
+        if getattr(self, "_ctx", None):
+            lib.pt_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        self.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- the path -----------------------------------------------------------
+    def upload(self, objs: Sequence[Object]):
+        arr = to_c_array(objs)
+        check(lib.pt_scene_upload(self._ctx, arr, len(objs)), self._ctx)
+        self.n_objects = len(objs)
+
+    def trace(self, iters: int = 1):
+        """`iters` applications of traceCanvas (src/Lib.hs:58-65)."""
+        check(lib.pt_trace(self._ctx, iters), self._ctx)
+
+    def reset(self):
+        check(lib.pt_reset(self._ctx), self._ctx)
+
+    def synchronize(self):
+        check(lib.pt_synchronize(self._ctx), self._ctx)
+
+    def read_sum(self) -> np.ndarray:
+        """Element `samples_done` of Lib.traces: (H, W, 3) float64 SUM of samples."""
+        out = np.empty(self.shape, dtype=np.float64)
+        check(lib.pt_read_sum(self._ctx, out.ctypes.data_as(C.c_void_p)), self._ctx)
+        return out
+
+    def read_sum_f32(self) -> np.ndarray:
+        out = np.empty(self.shape, dtype=np.float32)
+        check(lib.pt_read_sum_f32(self._ctx, out.ctypes.data_as(C.c_void_p)), self._ctx)
+        return out
+
+    def write_sum_f32(self, canvas: np.ndarray, samples_done: int = 0):
+        a = np.ascontiguousarray(canvas, dtype=np.float32)
+        assert a.shape == self.shape
+        check(lib.pt_write_sum_f32(self._ctx, a.ctypes.data_as(C.c_void_p), samples_done), self._ctx)
+
+    def read_rgb8(self, mode: int = _lib.PT_RGB8_REFERENCE) -> np.ndarray:
+        """repa3ToImage: array (W, H, 3) uint8 = rows of an image H wide, W tall."""
+        out = np.empty((self.params.width, self.params.height, 3), dtype=np.uint8)
+        check(lib.pt_read_rgb8(self._ctx, out.ctypes.data_as(C.c_void_p), mode), self._ctx)
+        return out
+
+    def primary_hits(self):
+        H, W = self.params.height, self.params.width
+        idx = np.empty((H, W), dtype=np.int32)
+        t = np.empty((H, W), dtype=np.float64)
+        nrm = np.empty((H, W, 3), dtype=np.float64)
+        check(lib.pt_primary_hits(self._ctx, idx.ctypes.data_as(C.c_void_p), t.ctypes.data_as(C.c_void_p),
+                                  nrm.ctypes.data_as(C.c_void_p)), self._ctx)
+        return idx, t, nrm
+
+    @property
+    def segments(self) -> int:
+        v = C.c_uint64()
+        check(lib.pt_segments(self._ctx, C.byref(v)), self._ctx)
+        return v.value
+
+    @property
+    def samples_done(self) -> int:
+        v = C.c_int64()
+        check(lib.pt_samples_done(self._ctx, C.byref(v)), self._ctx)
+        return v.value
+
+    # -- device-side access -------------------------------------------------
+    def canvas_device_ptr(self):
+        p, n = C.c_void_p(), C.c_size_t()
+        check(lib.pt_canvas_device_ptr(self._ctx, C.byref(p), C.byref(n)), self._ctx)
+        return p.value, n.value
+
+    def set_stream(self, hip_stream: int):
+        check(lib.pt_set_stream(self._ctx, C.c_void_p(hip_stream)), self._ctx)
+
+    def rgb8_device(self, d_out: int, mode: int = _lib.PT_RGB8_REFERENCE, samples: int = 0):
+        check(lib.pt_rgb8_device(self._ctx, C.c_void_p(d_out), mode, samples), self._ctx)
+
+    def set_timing(self, on: bool = True):
+        check(lib.pt_set_timing(self._ctx, 1 if on else 0), self._ctx)
+
+    def last_trace_ms(self):
+        ms, n = C.c_float(), C.c_int32()
+        check(lib.pt_last_trace_ms(self._ctx, C.byref(ms), C.byref(n)), self._ctx)
+        return ms.value, n.value
+
+    # -- device-function parity hooks --------------------------------------
+    def dev_diffuse(self, normal, u):
+        normal = np.ascontiguousarray(normal, dtype=np.float32)
+        u = np.ascontiguousarray(u, dtype=np.float32)
+        out = np.empty_like(normal)
+        check(lib.pt_dev_diffuse(self._ctx, len(normal), normal.ctypes.data_as(C.c_void_p),
+                                 u.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p)), self._ctx)
+        return out
+
+    def dev_specular(self, vector, normal, u, noise: float = -1.0):
+        vector = np.ascontiguousarray(vector, dtype=np.float32)
+        normal = np.ascontiguousarray(normal, dtype=np.float32)
+        u = np.ascontiguousarray(u, dtype=np.float32)
+        out = np.empty_like(vector)
+        check(lib.pt_dev_specular(self._ctx, len(vector), vector.ctypes.data_as(C.c_void_p),
+                                  normal.ctypes.data_as(C.c_void_p), u.ctypes.data_as(C.c_void_p),
+                                  noise, out.ctypes.data_as(C.c_void_p)), self._ctx)
+        return out
+
+    def dev_distance(self, obj: Object, origin, vector):
+        origin = np.ascontiguousarray(origin, dtype=np.float32)
+        vector = np.ascontiguousarray(vector, dtype=np.float32)
+        out = np.empty(len(origin), dtype=np.float32)
+        co = obj.to_c()
+        check(lib.pt_dev_distance(self._ctx, len(origin), C.byref(co), origin.ctypes.data_as(C.c_void_p),
+                                  vector.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p)), self._ctx)
+        return out
+
+    def dev_philox(self, c0, c1, key: int):
+        c0 = np.ascontiguousarray(c0, dtype=np.uint32)
+        c1 = np.ascontiguousarray(c1, dtype=np.uint32)
+        out = np.empty((len(c0), 2), dtype=np.uint32)
+        check(lib.pt_dev_philox(self._ctx, len(c0), c0.ctypes.data_as(C.c_void_p),
+                                c1.ctypes.data_as(C.c_void_p), key, out.ctypes.data_as(C.c_void_p)), self._ctx)
+        return out
+
+
+def traces(params: Params, objs: Optional[Sequence[Object]] = None, **kw) -> Iterator[np.ndarray]:
+    """Lib.traces (src/Lib.hs:53-56): element k is the (H, W, 3) float64 sum of
+    k samples per pixel; element 0 is the black canvas.  Lazy, like the list:
+    pulling element k+1 runs one more traceCanvas on the GPU."""
+    with Renderer(params, objs, **kw) as r:
+        yield r.read_sum()
+        while True:
+            r.trace(1)
+            yield r.read_sum()
+
+
+def repa3ToImage(renderer: Renderer, mode: int = _lib.PT_RGB8_REFERENCE) -> np.ndarray:
+    """Conversion.repa3ToImage (src/Conversion.hs:22-28) of the renderer's
+    current canvas: uint8 rows of an image Params.height wide, Params.width tall."""
+    return renderer.read_rgb8(mode)

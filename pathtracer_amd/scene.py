@@ -1,0 +1,100 @@
+"""Scene and parameter types with the reference's names.
+
+`Params` mirrors src/Params.hs:3-11, `Object`/`Disk`/`InfinitePlane` mirror
+src/Object.hs:30-56, and `objects` is the reference's hard-coded scene
+(src/Object.hs:104-148) -- here they are run-time values handed to libpt.
+"""
+from dataclasses import dataclass, field
+from typing import Sequence, Tuple, Union
+
+from . import _lib
+
+Vec = Tuple[float, float, float]
+
+
+@dataclass
+class Params:
+    height: int = 500           # src/Params.hs:3
+    width: int = 500            # src/Params.hs:5
+    cameraDepth: float = 500.0  # src/Params.hs:7
+    numIters: int = 10          # src/Params.hs:9
+    maxBounces: int = 30        # src/Params.hs:11
+
+
+@dataclass
+class InfinitePlane:            # src/Object.hs:55-56
+    point: Vec
+    normal: Vec
+
+
+@dataclass
+class Disk:                     # src/Object.hs:52-54
+    center: Vec
+    normal: Vec
+    radius: float
+
+
+Form = Union[InfinitePlane, Disk]
+
+
+@dataclass
+class Object:                   # src/Object.hs:30-36
+    color: Vec
+    emittance: float
+    reflective: bool
+    form: Form
+    name: str = ""
+
+    def to_c(self) -> _lib.pt_object:
+        o = _lib.pt_object()
+        f = self.form
+        if isinstance(f, Disk):
+            o.kind, pt, o.radius = _lib.PT_DISK, f.center, float(f.radius)
+        elif isinstance(f, InfinitePlane):
+            o.kind, pt, o.radius = _lib.PT_INFINITE_PLANE, f.point, 0.0
+        else:
+            raise TypeError(f"unknown Form {type(f).__name__}")
+        o.reflective = 1 if self.reflective else 0
+        o.point[:] = [float(x) for x in pt]
+        o.normal[:] = [float(x) for x in f.normal]
+        o.color[:] = [float(x) for x in self.color]
+        o.emittance = float(self.emittance)
+        return o
+
+
+def to_c_array(objs: Sequence[Object]):
+    arr = (_lib.pt_object * len(objs))()
+    for k, o in enumerate(objs):
+        arr[k] = o.to_c()
+    return arr
+
+
+# src/Object.hs:82-145, same names
+infLight = Object((1, 1, 1), 5, True, InfinitePlane((0, 0, -10), (0, 0, -1)), "infinite light")
+disk = Object((0, 1, 0), 0, False, Disk((0, 0, 10), (1, 0, -1), 600), "disk")
+light = Object((1, 1, 1), 2, True, Disk((0, 0, -1), (0, 0, 1), 20), "light")
+infPlane = Object((1, 1, 1), 0, False, InfinitePlane((20, -20, 100), (0, 0, -1)), "plane 1")
+infPlane2 = Object((0.1, 1, 1), 0, False, InfinitePlane((20, -20, 100), (0, 1, 0)), "plane 2")
+infPlane3 = Object((1, 1, 0.1), 0, False, InfinitePlane((20, -20, 100), (-1, 0, 0)), "plane 3")
+
+# objects = V.fromList [infPlane, infPlane2, infPlane3, light]  (src/Object.hs:147-148)
+objects = [infPlane, infPlane2, infPlane3, light]
+
+
+def random_disk_scene(n: int, seed: int):
+    """Synthetic n-object scene of SURVEY.md 8(d) (disk variant, expressible by
+    the reference's Form): object 0 is a back plane at z=1500, the rest are
+    disks with random unit normals in x,y in [-400,400], z in [200,1200];
+    radii U(5,40); colour U(0.2,1)^3; half reflective; 2% emissive U(1,5)."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    objs = [Object((1, 1, 1), 0, False, InfinitePlane((0, 0, 1500), (0, 0, -1)), "back plane")]
+    for k in range(1, n):
+        c = (rng.uniform(-400, 400), rng.uniform(-400, 400), rng.uniform(200, 1200))
+        nrm = rng.normal(size=3)
+        nrm = tuple(float(x) for x in nrm / np.linalg.norm(nrm))
+        emit = float(rng.uniform(1, 5)) if rng.uniform() < 0.02 else 0.0
+        objs.append(Object(tuple(float(x) for x in rng.uniform(0.2, 1, size=3)), emit,
+                           bool(rng.uniform() < 0.5), Disk(tuple(float(x) for x in c), nrm,
+                                                            float(rng.uniform(5, 40))), f"disk {k}"))
+    return objs

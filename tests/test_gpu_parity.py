@@ -1,0 +1,355 @@
+"""GPU parity tests: the HIP path (through the C ABI, libpt.so) against the CPU
+oracle, which is an fp64 RESTATEMENT of the reference (oracle/pt_oracle.h), on
+the same seeded inputs.
+
+Bars (BASELINE.json north_star):
+  * integer / index / byte results bit-exact: Philox words, primary-hit object
+    indices, RGB8 bytes;
+  * primary-hit t and normals within 1e-5 relative;
+  * fp32 device functions (intersection, scatter) within the tolerance written
+    in each test;
+  * images: path-wise agreement with the oracle on the SAME Philox stream, and
+    statistical agreement with the oracle on the reference's own StdGen stream
+    (thresholds from SURVEY.md 8c, fixed here).
+"""
+import numpy as np
+import pytest
+
+import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pa():
+    import pathtracer_amd
+    return pathtracer_amd
+
+
+@pytest.fixture(scope="module")
+def small(pa):
+    r = pa.Renderer(pa.Params(8, 8, 500.0, 1, 4))
+    yield r
+    r.close()
+
+
+# ---------------------------------------------------------------- RNG --------
+def test_philox_bit_exact(small):
+    rng = np.random.default_rng(1)
+    c0 = rng.integers(0, 2**32, 4096, dtype=np.uint64).astype(np.uint32)
+    c1 = rng.integers(0, 2**32, 4096, dtype=np.uint64).astype(np.uint32)
+    c0[:3] = [0, 0xFFFFFFFF, 0x243F6A88]
+    c1[:3] = [0, 0xFFFFFFFF, 0x85A308D3]
+    key = 0x13198A2E
+    dev = small.dev_philox(c0, c1, key)
+    out = (O.C.c_uint32 * 2)()
+    for k in range(len(c0)):
+        O.L.o_philox2x32_10(int(c0[k]), int(c1[k]), key, out)
+        assert (int(dev[k, 0]), int(dev[k, 1])) == (out[0], out[1])
+    # Random123 known answer, key 0x13198a2e, ctr (243f6a88, 85a308d3)
+    assert (int(dev[2, 0]), int(dev[2, 1])) == (0xDD7CE038, 0xF62A4C12)
+
+
+# ------------------------------------------------------------ geometry -------
+@pytest.mark.parametrize("H,W,depth", [(200, 200, 500.0), (64, 64, 500.0), (301, 257, 500.0), (33, 17, 40.0),
+                                        (1, 1, 500.0), (540, 960, 500.0)])
+def test_primary_hits_default_scene(pa, H, W, depth):
+    with pa.Renderer(pa.Params(H, W, depth, 1, 4)) as r:
+        idx, t, nrm = r.primary_hits()
+    oidx, ot, onrm = O.primary_hits(O.params(H, W, depth, 4), O.default_scene())
+    assert np.array_equal(idx, oidx)                     # bit-exact, tie lines included
+    hit = oidx >= 0
+    assert np.all(np.abs(t[hit] - ot[hit]) <= 1e-5 * np.abs(ot[hit]))
+    assert np.all(np.abs(nrm - onrm) <= 1e-5)
+    # the fp64 device path follows the reference's operation order: not just close
+    assert np.array_equal(t, ot)
+
+
+def test_primary_hits_tie_lines(pa):
+    """Columns j = W/2-100 and rows i = H/2-100 tie in exact arithmetic
+    (SURVEY.md 7): the winner is decided by fp64 rounding and must still match."""
+    H = W = 500
+    with pa.Renderer(pa.Params(H, W, 500.0, 1, 4)) as r:
+        idx, t, _ = r.primary_hits()
+    oidx, ot, _ = O.primary_hits(O.params(H, W, 500.0, 4), O.default_scene())
+    assert np.array_equal(idx[:, W // 2 - 100], oidx[:, W // 2 - 100])
+    assert np.array_equal(idx[H // 2 - 100, :], oidx[H // 2 - 100, :])
+    assert np.array_equal(idx, oidx)
+    assert idx[H // 2, W // 2] == 0 and t[H // 2, W // 2] == 100.0     # analytic KAT
+
+
+@pytest.mark.parametrize("n,seed", [(5, 1), (8, 2), (9, 3), (100, 4), (1000, 1)])
+def test_primary_hits_random_disks(pa, n, seed):
+    objs = pa.random_disk_scene(n, seed)
+    H, W = 96, 128
+    with pa.Renderer(pa.Params(H, W, 120.0, 1, 4), objs) as r:
+        idx, t, nrm = r.primary_hits()
+    oidx, ot, onrm = O.primary_hits(O.params(H, W, 120.0, 4), O.scene_from(objs))
+    assert np.array_equal(idx, oidx)
+    assert np.array_equal(t, ot)
+    assert np.array_equal(nrm, onrm)
+    assert len(np.unique(oidx)) > (2 if n > 8 else 1)     # the scene is actually visible
+
+
+def _rand_vecs(rng, n, scale=1.0):
+    return (rng.normal(size=(n, 3)) * scale).astype(np.float32)
+
+
+def test_dev_distance_plane_and_disk(pa, small):
+    rng = np.random.default_rng(7)
+    n = 20000
+    org = _rand_vecs(rng, n, 50.0)
+    vec = _rand_vecs(rng, n, 1.0)
+    for obj in (pa.infPlane, pa.infPlane2, pa.light, pa.disk,
+                pa.Object((1, 1, 1), 0, False, pa.InfinitePlane((3, -2, 9), (0.3, -2.0, 1.1)))):
+        dev = small.dev_distance(obj, org, vec)
+        arr = O.scene_from([obj])
+        bad = 0
+        for k in range(n):
+            d = O.C.c_double()
+            ok = O.L.o_distance_from(O.vec(org[k]), O.vec(vec[k]), arr, O.C.byref(d))
+            if ok != (not np.isnan(dev[k])):
+                # an fp32/fp64 disagreement is legitimate only on a guard boundary
+                bad += 1
+                continue
+            if ok:
+                assert abs(dev[k] - d.value) <= 2e-5 * abs(d.value) + 1e-6, (obj.name, k, dev[k], d.value)
+        assert bad <= n * 2e-3, (obj.name, bad)
+
+
+def test_dev_diffuse(small):
+    rng = np.random.default_rng(8)
+    n = 20000
+    nrm = _rand_vecs(rng, n, 1.0) * rng.uniform(0.2, 3.0, size=(n, 1)).astype(np.float32)
+    nrm[:6] = [[0, 0, -1], [0, 1, 0], [-1, 0, 0], [0, 0, 1], [0, 0, 2.5], [1, 0, -1]]
+    u = rng.integers(0, 2**24, size=(n, 2)).astype(np.float32) / np.float32(2**24)
+    dev = small.dev_diffuse(nrm, u)
+    for k in range(n):
+        ref = O.L.o_diffuse_u(float(u[k, 0]), float(u[k, 1]), O.vec(nrm[k])).t()
+        ln = np.linalg.norm(nrm[k].astype(np.float64))
+        # fp32 rotation with hardware sin/cos: absolute 2e-5 of the vector's length
+        assert np.max(np.abs(dev[k] - np.array(ref))) <= 2e-5 * ln, (k, dev[k], ref)
+
+
+def test_dev_specular(small):
+    rng = np.random.default_rng(9)
+    n = 20000
+    vec = _rand_vecs(rng, n, 1.0) * rng.uniform(0.2, 3.0, size=(n, 1)).astype(np.float32)
+    nrm = _rand_vecs(rng, n, 1.0) * rng.uniform(0.2, 3.0, size=(n, 1)).astype(np.float32)
+    vec[:4] = [[0, 0, 1], [0, 0, -1], [1, 0, 0], [0.3, 0.4, -0.5]]
+    nrm[:4] = [[0, 0, 1], [0, 0, 1], [0, 0, 1], [0, 0, 1]]
+    u = rng.integers(0, 2**24, size=(n, 2)).astype(np.float32) / np.float32(2**24)
+    dev = small.dev_specular(vec, nrm, u)
+    worst = 0.0
+    for k in range(n):
+        ref = np.array(O.L.o_specular_u(float(u[k, 0]), float(u[k, 1]), 40.0, O.vec(vec[k]), O.vec(nrm[k])).t())
+        ln = np.linalg.norm(vec[k].astype(np.float64))
+        worst = max(worst, np.max(np.abs(dev[k] - ref)) / ln)
+    # polynomial asin + hardware sin/cos/rsq in fp32
+    assert worst <= 5e-5, worst
+    # propSpecular (test/Spec.hs:144-155): noise 0 => mirror law
+    dev0 = small.dev_specular(vec, nrm, u, noise=0.0)
+    nh = nrm / np.linalg.norm(nrm, axis=1, keepdims=True)
+    vin = vec / np.linalg.norm(vec, axis=1, keepdims=True)
+    vout = dev0 / np.linalg.norm(dev0, axis=1, keepdims=True)
+    assert np.max(np.abs(np.sum(-vin * nh, axis=1) - np.sum(vout * nh, axis=1))) < 1e-4
+    proj = lambda v: v - np.sum(v * nh, axis=1, keepdims=True) * nh
+    assert np.max(np.abs(proj(vec) - proj(dev0))) < 1e-4 * 3.0
+
+
+# ------------------------------------------------------------- images --------
+def _mismatch_fraction(dev_sum, ora_sum, rel=2e-4, abs_=1e-5):
+    bad = np.abs(dev_sum - ora_sum) > (rel * np.abs(ora_sum) + abs_)
+    return bad.any(axis=2).mean()
+
+
+@pytest.mark.parametrize("flags", [0, 1])
+@pytest.mark.parametrize("H,W,spp,bounces", [(64, 64, 8, 4), (200, 200, 16, 4), (48, 80, 4, 8), (31, 29, 5, 30)])
+def test_pathwise_parity_same_stream(pa, H, W, spp, bounces, flags):
+    """Same Philox draws on both sides: every path takes the same decisions
+    unless an fp32/fp64 rounding difference flips a hit, so almost every pixel
+    sum must agree to fp32 accuracy."""
+    with pa.Renderer(pa.Params(H, W, 500.0, spp, bounces), seed=11, flags=flags) as r:
+        r.trace(spp)
+        dev = r.read_sum()
+        segs = r.segments
+    p = O.params(H, W, 500.0, bounces, O.PHILOX, 11)
+    tr = O.Tracer(p, O.default_scene())
+    ora = tr.trace(spp)
+    assert _mismatch_fraction(dev, ora) <= 0.01
+    assert abs(dev.mean() - ora.mean()) <= 2e-3 * ora.mean()
+    # closest-hit searches: the reference's count, minus the reused primary
+    expect = tr.segments.value
+    if flags == 0:
+        expect = expect - H * W * spp + H * W
+    assert abs(segs - expect) <= 0.002 * expect
+
+
+@pytest.mark.parametrize("n,seed,bounces", [(6, 5, 6), (8, 6, 8), (40, 7, 6), (300, 8, 5)])
+def test_pathwise_parity_random_disks(pa, n, seed, bounces):
+    """Diffuse + specular mix, static (n <= 8) and dynamic object loops."""
+    objs = pa.random_disk_scene(n, seed)
+    H, W, spp = 40, 56, 6
+    with pa.Renderer(pa.Params(H, W, 60.0, spp, bounces), objs, seed=3) as r:
+        r.trace(spp)
+        dev = r.read_sum()
+    tr = O.Tracer(O.params(H, W, 60.0, bounces, O.PHILOX, 3), O.scene_from(objs))
+    ora = tr.trace(spp)
+    # specular chains amplify rounding differences more than diffuse ones
+    assert _mismatch_fraction(dev, ora, rel=1e-3, abs_=1e-4) <= 0.03
+    assert abs(dev.mean() - ora.mean()) <= 0.02 * max(ora.mean(), 1e-3)
+
+
+def test_statistical_parity_reference_stream(pa):
+    """Device (Philox) against the oracle on the reference's own StdGen stream:
+    independent estimates of the same image.  z = (mu_dev - mu_ref) /
+    sqrt(var/N + var/N_ref) per pixel and channel.  Thresholds:
+    fraction |z| > 4 below 1e-3; per-channel mean bias below 0.5 %; RMSE within
+    1.2x of the predicted value."""
+    H, W, B, N, NREF = 96, 96, 8, 256, 256
+    with pa.Renderer(pa.Params(H, W, 500.0, N, B), seed=5) as r:
+        r.trace(N)
+        mu_dev = r.read_sum() / N
+    tr = O.Tracer(O.params(H, W, 500.0, B, O.STDGEN), O.default_scene())
+    tr.trace(NREF)
+    mu_ref = tr.sum / NREF
+    var = np.maximum(tr.sumsq / NREF - mu_ref**2, 0.0) * NREF / (NREF - 1)
+    se2 = var / N + var / NREF
+    ok = se2 > 0
+    z = (mu_dev[ok] - mu_ref[ok]) / np.sqrt(se2[ok])
+    assert (np.abs(z) > 4).mean() < 1e-3
+    for k in range(3):
+        bias = abs(mu_dev[..., k].mean() - mu_ref[..., k].mean()) / mu_ref[..., k].mean()
+        assert bias < 5e-3, (k, bias)
+    rmse = np.sqrt(np.mean((mu_dev - mu_ref) ** 2))
+    pred = np.sqrt(np.mean(se2))
+    assert rmse <= 1.2 * pred, (rmse, pred)
+    assert rmse >= 0.5 * pred      # and the two estimates really are independent
+
+
+def test_max_bounces_one_is_black(pa):
+    """Analytic KAT: the only light is behind the camera, so
+    with maxBounces = 1 every pixel is black."""
+    for flags in (0, 1):
+        with pa.Renderer(pa.Params(32, 32, 500.0, 4, 1), flags=flags) as r:
+            r.trace(4)
+            assert not r.read_sum().any()
+
+
+def test_primary_light_scene(pa):
+    """A light in front of the camera: radiance = emittance * white, per sample."""
+    objs = [pa.Object((1, 1, 1), 3.0, True, pa.Disk((0, 0, 50), (0, 0, -1), 10.0), "front light"),
+            pa.infPlane]
+    for flags in (0, 1):
+        with pa.Renderer(pa.Params(64, 64, 500.0, 4, 4), objs, flags=flags) as r:
+            r.trace(4)
+            dev = r.read_sum()
+        tr = O.Tracer(O.params(64, 64, 500.0, 4, O.PHILOX, 0), O.scene_from(objs))
+        ora = tr.trace(4)
+        assert dev[32, 32, 0] == 12.0
+        assert _mismatch_fraction(dev, ora) <= 0.01
+
+
+def test_chunking_is_bit_exact(pa):
+    """k calls of pt_trace(1) == one call of pt_trace(k), bit for bit, and the
+    canvas is the running SUM (traces !! k), element 0 black."""
+    P = pa.Params(50, 70, 500.0, 6, 5)
+    with pa.Renderer(P, seed=2) as a, pa.Renderer(P, seed=2) as b:
+        assert not a.read_sum_f32().any()
+        a.trace(6)
+        for _ in range(6):
+            b.trace(1)
+        assert np.array_equal(a.read_sum_f32(), b.read_sum_f32())
+        assert a.samples_done == b.samples_done == 6
+        assert a.segments == b.segments - 5 * 50 * 70      # b recomputed the primary hit per launch
+        a.reset()
+        assert not a.read_sum_f32().any() and a.samples_done == 0 and a.segments == 0
+
+
+def test_traces_generator(pa):
+    """Lib.traces: element k = sum of k samples; element 0 black; lazily extended."""
+    P = pa.Params(16, 24, 500.0, 3, 4)
+    g = pa.traces(P, seed=4)
+    e0, e1, e2 = next(g), next(g), next(g)
+    g.close()
+    assert e0.shape == (16, 24, 3) and e0.dtype == np.float64 and not e0.any()
+    with pa.Renderer(P, seed=4) as r:
+        r.trace(1)
+        assert np.array_equal(r.read_sum(), e1)
+        r.trace(1)
+        assert np.array_equal(r.read_sum(), e2)
+
+
+def test_sample_split_union(pa):
+    """Multi-GPU sample split: contexts rendering global samples
+    {g, g+G, ...} sum to the single-context image up to fp32 summation order."""
+    P = pa.Params(40, 40, 500.0, 8, 6)
+    with pa.Renderer(P, seed=9) as full:
+        full.trace(8)
+        want = full.read_sum()
+        segs = full.segments
+    G = 4
+    got = np.zeros_like(want)
+    total = 0
+    for g in range(G):
+        with pa.Renderer(P, seed=9, sample_offset=g, sample_stride=G) as r:
+            r.trace(8 // G)
+            got += r.read_sum()
+            total += r.segments
+    assert np.allclose(got, want, rtol=1e-5, atol=1e-5)
+    assert total == segs + (G - 1) * 40 * 40
+
+
+# ------------------------------------------------------------- output --------
+def test_rgb8_reference_mode_bit_exact(pa):
+    """repa3ToImage + listToPixelRGB8: round-half-even(255*x), wrap mod 256,
+    transposed layout (j*H + i)*3 + k -- compared byte for byte."""
+    H, W = 70, 45
+    rng = np.random.default_rng(3)
+    canvas = rng.uniform(0, 3.0, size=(H, W, 3)).astype(np.float32)
+    flat = canvas.reshape(-1)
+    ties = (np.arange(0, 600) + 0.5) / 255.0               # exact .5 cases where representable
+    flat[: len(ties)] = ties.astype(np.float32)
+    flat[len(ties): len(ties) + 4] = [0.0, 1.0, 256.0 / 255.0, 1000.25]
+    with pa.Renderer(pa.Params(H, W, 500.0, 1, 4)) as r:
+        r.write_sum_f32(canvas, samples_done=3)
+        dev = r.read_rgb8(pa.PT_RGB8_REFERENCE)
+        mean = r.read_rgb8(pa.PT_RGB8_MEAN_CLAMP)
+        gam = r.read_rgb8(pa.PT_RGB8_MEAN_GAMMA)
+    p = O.params(H, W, 500.0, 4)
+    ora = O.repa3_to_image(p, canvas.astype(np.float64))
+    assert dev.shape == (W, H, 3)
+    assert np.array_equal(dev, ora)
+    want_mean = O.repa3_to_image(p, np.clip(canvas.astype(np.float64) * (1.0 / 3.0), 0, 1))
+    assert np.array_equal(mean, want_mean)
+    want_g = np.rint(255.0 * np.clip(canvas.astype(np.float64) * (1.0 / 3.0), 0, 1) ** (1 / 2.2))
+    assert np.max(np.abs(gam.astype(int) - want_g.transpose(1, 0, 2).astype(int))) <= 1
+
+
+@pytest.mark.parametrize("H,W", [(1, 1), (64, 64), (65, 63), (200, 3), (3, 200)])
+def test_rgb8_ragged_tiles(pa, H, W):
+    rng = np.random.default_rng(H * 1000 + W)
+    canvas = rng.uniform(0, 1.2, size=(H, W, 3)).astype(np.float32)
+    with pa.Renderer(pa.Params(H, W, 500.0, 1, 4)) as r:
+        r.write_sum_f32(canvas)
+        dev = r.read_rgb8()
+    assert np.array_equal(dev, O.repa3_to_image(O.params(H, W, 500.0, 4), canvas.astype(np.float64)))
+
+
+# -------------------------------------------------------------- errors -------
+def test_error_behaviour(pa):
+    with pytest.raises(pa.PtError) as e:
+        pa.Renderer(pa.Params(0, 8, 500.0, 1, 4))
+    assert e.value.status == -1
+    with pytest.raises(pa.PtError) as e:
+        pa.Renderer(pa.Params(8, 8, 500.0, 1, 65))
+    assert e.value.status == -5
+    with pytest.raises(pa.PtError):
+        pa.Renderer(pa.Params(8, 8, 500.0, 1, 4), device=99)
+    with pytest.raises(pa.PtError):
+        pa.Renderer(pa.Params(8, 8, 500.0, 1, 4), sample_offset=2, sample_stride=2)
+    with pa.Renderer(pa.Params(8, 8, 500.0, 1, 4)) as r:
+        with pytest.raises(pa.PtError):
+            r.trace(-1)
+        with pytest.raises(pa.PtError):
+            r.upload([])
