@@ -89,6 +89,7 @@ def main():
 
     import torch
     import pathtracer_amd as pa
+    from pathtracer_amd.distributed import allreduce_canvas, canvas_tensor, shard_samples
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: libpt has no CPU path")
@@ -98,30 +99,25 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
+    my_spp, s_off, s_stride = shard_samples(args.spp, rank, world)
     P = pa.Params(args.height, args.width, args.camera_depth, args.spp, args.bounces)
     flags = pa.PT_FLAG_NO_PRIMARY_REUSE if args.no_primary_reuse else 0
-    r = pa.Renderer(P, pa.objects, seed=0, device=local_rank, sample_offset=rank, sample_stride=world,
+    r = pa.Renderer(P, pa.objects, seed=0, device=local_rank, sample_offset=s_off, sample_stride=s_stride,
                     flags=flags)
     stream = torch.cuda.current_stream()
     r.set_stream(stream.cuda_stream)          # kernels, all-reduce and events share torch's stream
     r.set_timing(True)
 
     # the context's canvas as a torch tensor (no copy), for the all-reduce
-    ptr, nbytes = r.canvas_device_ptr()
-
-    class _Canvas:
-        __cuda_array_interface__ = {"shape": (nbytes // 4,), "typestr": "<f4", "data": (ptr, False),
-                                    "version": 2, "strides": None}
-    canvas = torch.as_tensor(_Canvas(), device=torch.device("cuda", local_rank))
+    canvas = canvas_tensor(r, local_rank)
     rgb = torch.empty(args.height * args.width * 3, dtype=torch.uint8, device="cuda")
 
-    my_spp = args.spp // world + (1 if rank < args.spp % world else 0)
 
     def step():
         r.reset()
         r.trace(my_spp)
         if dist is not None:
-            dist.all_reduce(canvas, op=dist.ReduceOp.SUM)
+            allreduce_canvas(canvas)
         if rank == 0:
             r.rgb8_device(rgb.data_ptr(), pa.PT_RGB8_MEAN_CLAMP, args.spp)
 
@@ -134,13 +130,11 @@ def main():
         step()
     fence()
     segs_step = torch.tensor([r.segments], dtype=torch.float64, device="cuda")
-    kernel_ms = []
 
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-        kernel_ms.append(None)
     fence()
     elapsed = time.perf_counter() - t0
 
