@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Regenerates the fixtures in this directory from the CPU oracle
+(oracle/pt_oracle.c, the fp64 restatement of the reference).
+
+The reference itself cannot produce golden vectors: it is Haskell and no GHC
+exists in the build image, and its own test suite holds no
+fixtures beyond the known answers restated in tests/test_oracle_spec.py.  These
+files therefore pin (a) the oracle against accidental change and (b) the GPU
+path against the oracle on the GPU box; what ties them to the reference is the
+analytic cross-check in tests/test_oracle_golden.py (hit regions derived
+independently from src/Object.hs:104-148 and src/Lib.hs:41-51).
+
+Run:  python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+import oracle as O  # noqa: E402
+
+
+def primary(H, W, depth, name):
+    idx, t, nrm = O.primary_hits(O.params(H, W, depth, 4), O.default_scene())
+    np.savez_compressed(os.path.join(HERE, name), idx=idx.astype(np.int8), t=t, normal=nrm.astype(np.int8),
+                        H=H, W=W, camera_depth=depth)
+
+
+def image(H, W, depth, bounces, spp, rng, seed, name):
+    tr = O.Tracer(O.params(H, W, depth, bounces, rng, seed), O.default_scene(), threads=4)
+    tr.trace(spp)
+    np.savez_compressed(os.path.join(HERE, name), sum=tr.sum, segments=tr.segments.value, H=H, W=W,
+                        camera_depth=depth, bounces=bounces, spp=spp, rng=rng, seed=seed)
+
+
+if __name__ == "__main__":
+    primary(64, 64, 500.0, "primary_default_64x64.npz")
+    primary(200, 200, 500.0, "primary_default_200x200.npz")
+    # BASELINE config 1: default scene, 200x200, 16 spp, depth 4, the reference's own StdGen stream
+    image(200, 200, 500.0, 4, 16, O.STDGEN, 0, "image_config1_stdgen_200x200_16spp_d4.npz")
+    # the device's Philox stream, for path-wise comparison on the GPU box
+    image(64, 64, 500.0, 8, 8, O.PHILOX, 11, "image_philox_64x64_8spp_d8_seed11.npz")
+    print("golden fixtures written to", HERE)

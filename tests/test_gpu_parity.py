@@ -363,3 +363,30 @@ def test_error_behaviour(pa):
             r.trace(-1)
         with pytest.raises(pa.PtError):
             r.upload([])
+
+
+# ----------------------------------------------------- committed fixtures ----
+def test_against_committed_golden_fixtures(pa):
+    """tests/golden/*.npz (written by make_golden.py from the oracle, cross-checked
+    analytically in test_oracle_golden.py): primary hits bit-exact, Philox-stream
+    image path-wise equal."""
+    import os
+    G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    for name in ("primary_default_64x64.npz", "primary_default_200x200.npz"):
+        f = np.load(os.path.join(G, name))
+        with pa.Renderer(pa.Params(int(f["H"]), int(f["W"]), float(f["camera_depth"]), 1, 4)) as r:
+            idx, t, nrm = r.primary_hits()
+        assert np.array_equal(idx, f["idx"]) and np.array_equal(t, f["t"]) and np.array_equal(nrm, f["normal"])
+    f = np.load(os.path.join(G, "image_philox_64x64_8spp_d8_seed11.npz"))
+    with pa.Renderer(pa.Params(64, 64, 500.0, 8, 8), seed=11) as r:
+        r.trace(8)
+        dev = r.read_sum()
+    assert _mismatch_fraction(dev, f["sum"]) <= 0.01
+    # BASELINE config 1 (200x200, 16 spp, depth 4) against the oracle on the reference's StdGen
+    # stream: independent estimates, so only image-wide statistics are comparable at 16 spp
+    f = np.load(os.path.join(G, "image_config1_stdgen_200x200_16spp_d4.npz"))
+    with pa.Renderer(pa.Params(200, 200, 500.0, 16, 4), seed=0) as r:
+        r.trace(16)
+        dev = r.read_sum()
+    for k in range(3):
+        assert abs(dev[..., k].mean() - f["sum"][..., k].mean()) <= 0.01 * f["sum"][..., k].mean()
