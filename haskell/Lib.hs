@@ -1,0 +1,115 @@
+{-# LANGUAGE ForeignFunctionInterface #-}
+-- Lib.hs -- drop-in replacement for the reference's src/Lib.hs whose `traces`
+-- is computed by libpt.so (HIP kernels on an MI355X) instead of the recursive
+-- Haskell bounce loop.  app/Write.hs and app/Web.hs import `traces` unchanged.
+--
+-- NOT COMPILED in the build image (no GHC there, SURVEY.md F1): this is the
+-- binding a maintainer adds; include/pt.h is authoritative for the C side and
+-- INTEGRATION.md explains the cabal changes (extra-libraries: pt).
+--
+-- `bounceRay`, `reflectVector` and `specular` stay exported from the pure
+-- module LibPure (the reference's old Lib.hs, renamed) for test/Spec.hs.
+module Lib
+  ( bounceRay
+  , reflectVector
+  , specular
+  , traces
+  ) where
+
+import           Data.Array.Repa        ((:.) (..), Array, D, DIM3, U, Z (..))
+import qualified Data.Array.Repa        as R
+import qualified Data.Vector            as V
+import qualified Data.Vector.Storable   as VS
+import           Data.Int               (Int32, Int64)
+import           Data.Word              (Word32)
+import           Foreign
+import           Foreign.C.String       (CString, peekCString)
+import           Foreign.C.Types
+import           System.IO.Unsafe       (unsafePerformIO)
+
+import           LibPure                (bounceRay, reflectVector, specular)
+import           Object                 (Color (..), Form (..), Object (..), Point (..), Vector (..), objects)
+import qualified Params
+import           Triple                 (Triple (..))
+
+data PtCtx
+
+-- pt_params / pt_object, field for field as in include/pt.h
+data PtParams = PtParams
+  { ppHeight, ppWidth :: Int32, ppCameraDepth :: Double, ppMaxBounces :: Int32
+  , ppSeed :: Word32, ppDevice, ppSampleOffset, ppSampleStride, ppFlags :: Int32 }
+
+instance Storable PtParams where
+  sizeOf _ = 40
+  alignment _ = 8
+  peek _ = error "PtParams: write-only"
+  poke p (PtParams h w d b s dev off str fl) = do
+    pokeByteOff p 0 h; pokeByteOff p 4 w; pokeByteOff p 8 d; pokeByteOff p 16 b
+    pokeByteOff p 20 s; pokeByteOff p 24 dev; pokeByteOff p 28 off; pokeByteOff p 32 str
+    pokeByteOff p 36 fl
+
+newtype PtObject = PtObject Object
+
+instance Storable PtObject where
+  sizeOf _ = 96
+  alignment _ = 8
+  peek _ = error "PtObject: write-only"
+  poke p (PtObject (Object (Color (Triple r g b)) emit refl form _name)) = do
+    let (kind, Point (Triple px py pz), Vector (Triple nx ny nz), radius) = case form of
+          InfinitePlane pt n -> (0 :: Int32, pt, n, 0)
+          Disk c n rad       -> (1 :: Int32, c, n, rad)
+    pokeByteOff p 0 kind
+    pokeByteOff p 4 (if refl then 1 else 0 :: Int32)
+    mapM_ (\(k, x) -> pokeByteOff p (8 + 8 * k) (x :: Double))  (zip [0 ..] [px, py, pz])
+    mapM_ (\(k, x) -> pokeByteOff p (32 + 8 * k) (x :: Double)) (zip [0 ..] [nx, ny, nz])
+    pokeByteOff p 56 (radius :: Double)
+    mapM_ (\(k, x) -> pokeByteOff p (64 + 8 * k) (x :: Double)) (zip [0 ..] [r, g, b])
+    pokeByteOff p 88 (emit :: Double)
+
+-- `safe`: a call lasts milliseconds to seconds and `web` runs -threaded
+-- (pathtracer.cabal:37); Warp's other threads must keep running meanwhile.
+foreign import ccall safe "pt_create"       c_pt_create       :: Ptr (Ptr PtCtx) -> Ptr PtParams -> IO CInt
+foreign import ccall safe "pt_scene_upload" c_pt_scene_upload :: Ptr PtCtx -> Ptr PtObject -> Int32 -> IO CInt
+foreign import ccall safe "pt_trace"        c_pt_trace        :: Ptr PtCtx -> Int32 -> IO CInt
+foreign import ccall safe "pt_read_sum"     c_pt_read_sum     :: Ptr PtCtx -> Ptr Double -> IO CInt
+foreign import ccall safe "pt_last_error"   c_pt_last_error   :: Ptr PtCtx -> IO CString
+foreign import ccall safe "&pt_destroy"     p_pt_destroy      :: FunPtr (Ptr PtCtx -> IO ())
+
+check :: Ptr PtCtx -> CInt -> IO ()
+check _ 0 = return ()
+check ctx st = do
+  msg <- c_pt_last_error ctx >>= peekCString
+  ioError (userError ("libpt status " ++ show st ++ ": " ++ msg))
+
+-- One context for the process, created on first use from Params.* and Object.objects.
+{-# NOINLINE context #-}
+context :: ForeignPtr PtCtx
+context = unsafePerformIO $ alloca $ \pp -> with params $ \ppar -> do
+  c_pt_create pp ppar >>= check nullPtr
+  ctx <- peek pp
+  withArrayLen (map PtObject (V.toList objects)) $ \n arr ->
+    c_pt_scene_upload ctx arr (fromIntegral n) >>= check ctx
+  newForeignPtr p_pt_destroy ctx
+  where
+    params = PtParams (fromIntegral Params.height) (fromIntegral Params.width) Params.cameraDepth
+                      (fromIntegral Params.maxBounces) 0 0 0 1 0
+
+-- Element k of `traces`: forces k-1 first (the list is built by lazy IO in
+-- order), runs ONE more traceCanvas on the GPU and reads the running sum.
+element :: Int -> Array D DIM3 Double
+element k = unsafePerformIO $ withForeignPtr context $ \ctx -> do
+  if k > 0 then c_pt_trace ctx 1 >>= check ctx else return ()
+  let n = Params.height * Params.width * 3
+  fp <- mallocForeignPtrArray n
+  withForeignPtr fp $ \buf -> c_pt_read_sum ctx buf >>= check ctx
+  let v = VS.unsafeFromForeignPtr0 fp n
+      sh = Z :. Params.height :. Params.width :. 3
+  return $ R.fromFunction sh (\ix -> v VS.! R.toIndex sh ix)
+
+-- traces :: [Array D DIM3 Double]  (src/Lib.hs:53-56): element k is the SUM of
+-- k samples per pixel; element 0 is the black canvas.  `seqList` keeps the GPU
+-- state in step with the list position.
+traces :: [Array D DIM3 Double]
+traces = go 0
+  where
+    go k = let e = element k in e `seq` (e : go (k + 1))

@@ -1,0 +1,59 @@
+// write.cpp -- C++ twin of app/Write.hs:24-28:
+//     main = savePngImage "image.png" . ImageRGB8 . repa3ToImage $ traces !! Params.numIters
+// with Params (src/Params.hs:3-11) settable at run time.  All rendering runs
+// on the GPU through libpt.so; without a GPU this program fails with libpt's
+// error, it has no CPU path.
+//
+// usage: write [--height H] [--width W] [--camera-depth D] [--iters N] [--bounces B]
+//              [--seed S] [--mode reference|mean|gamma] [--out image.png] [--device K]
+#include "pathtracer.hpp"
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+using namespace pathtracer;
+
+int main(int argc, char **argv)
+{
+    Params p;                        // the reference's defaults: 500x500, depth 500, 10 iters, 30 bounces
+    std::string out = "image.png";
+    uint32_t seed = 0;
+    int mode = PT_RGB8_REFERENCE, device = 0;
+    for (int i = 1; i < argc; ++i) {
+        auto arg = [&](const char *name) { return !std::strcmp(argv[i], name) && i + 1 < argc; };
+        if (arg("--height")) p.height = std::atoi(argv[++i]);
+        else if (arg("--width")) p.width = std::atoi(argv[++i]);
+        else if (arg("--camera-depth")) p.cameraDepth = std::atof(argv[++i]);
+        else if (arg("--iters")) p.numIters = std::atoi(argv[++i]);
+        else if (arg("--bounces")) p.maxBounces = std::atoi(argv[++i]);
+        else if (arg("--seed")) seed = (uint32_t)std::strtoul(argv[++i], nullptr, 10);
+        else if (arg("--device")) device = std::atoi(argv[++i]);
+        else if (arg("--out")) out = argv[++i];
+        else if (arg("--mode")) {
+            const std::string m = argv[++i];
+            mode = m == "mean" ? PT_RGB8_MEAN_CLAMP : m == "gamma" ? PT_RGB8_MEAN_GAMMA : PT_RGB8_REFERENCE;
+        } else {
+            std::fprintf(stderr, "write: unknown argument %s\n", argv[i]);
+            return 2;
+        }
+    }
+    try {
+        Lib::Traces traces(p, objects(), seed, device);
+        const auto t0 = std::chrono::steady_clock::now();
+        traces.advance(p.numIters);                                   // traces !! Params.numIters
+        const Conversion::Image img = Conversion::repa3ToImage(traces, mode);
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        Conversion::savePngImage(out, img);
+        const uint64_t segs = traces.segments();
+        std::printf("{\"image\": \"%s\", \"width_px\": %d, \"height_px\": %d, \"iters\": %d, \"max_bounces\": %d, "
+                    "\"segments\": %llu, \"render_ms\": %.3f, \"mrays_per_s\": %.1f}\n",
+                    out.c_str(), img.width, img.height, p.numIters, p.maxBounces, (unsigned long long)segs, ms,
+                    segs / (ms * 1e3));
+    } catch (const std::exception &e) {
+        std::fprintf(stderr, "write: %s\n", e.what());
+        return 1;
+    }
+    return 0;
+}

@@ -26,7 +26,7 @@ struct pt_ctx {
     uint8_t *d_rgb = nullptr;
     int n_obj = 0;
     bool has_specular = false;
-    StaticGeom sg{};
+    std::vector<float4> h_geom;   // host copy: small scenes ride in the kernel arguments
     int64_t samples_done = 0;
     bool timing = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -259,10 +259,7 @@ int pt_scene_upload(pt_ctx *c, const pt_object *objs, int32_t n)
     PT_HIP(c, hipMemcpy(c->d_geom, geom.data(), geom.size() * sizeof(float4), hipMemcpyHostToDevice));
     PT_HIP(c, hipMemcpy(c->d_mat, mat.data(), mat.size() * sizeof(float4), hipMemcpyHostToDevice));
     PT_HIP(c, hipMemcpy(c->d_prim, prim.data(), prim.size() * sizeof(double), hipMemcpyHostToDevice));
-    std::memset(&c->sg, 0, sizeof c->sg);
-    if (n <= MAX_STATIC_OBJECTS)
-        for (int k = 0; k < n; ++k)
-            for (int f = 0; f < 3; ++f) c->sg.g[k][f] = geom[(size_t)k * 3 + f];
+    c->h_geom = geom;
     c->n_obj = n;
     c->has_specular = spec;
     return PT_OK;
@@ -293,7 +290,7 @@ int pt_trace(pt_ctx *c, int32_t iters)
         a.sample_begin = (uint32_t)(c->p.sample_offset + c->samples_done * c->p.sample_stride);
         a.sample_stride = (uint32_t)c->p.sample_stride;
         a.n_samples = n;
-        PT_HIP(c, launch_trace(a, c->sg, reuse, c->has_specular, c->stream));
+        PT_HIP(c, launch_trace(a, c->h_geom.data(), reuse, c->has_specular, c->stream));
         c->samples_done += n;
         left -= n;
         ++launches;

@@ -13,8 +13,8 @@ namespace pt {
 // the closest-hit loop indexes objects with a wave-uniform index, so hipcc
 // fetches these with s_load into SGPRs and the VALU reads them as scalar
 // operands -- no VGPRs and no LDS bandwidth spent on the object list.
-struct StaticGeom {
-    float4 g[MAX_STATIC_OBJECTS][3];
+template <int NS> struct StaticGeom {
+    float4 g[NS > 0 ? NS : 1][3];
 };
 
 struct TraceArgs {
@@ -34,7 +34,7 @@ struct TraceArgs {
 };
 
 // Launchers (pt_kernels.hip).  All return the hipError_t of the launch.
-hipError_t launch_trace(const TraceArgs &a, const StaticGeom &sg, bool reuse_primary,
+hipError_t launch_trace(const TraceArgs &a, const float4 *geom_host, bool reuse_primary,
                         bool has_specular, hipStream_t s);
 hipError_t launch_primary(const double *prim, int n_obj, int H, int W, double camera_depth,
                           int32_t *idx, double *t, double *normal, hipStream_t s);

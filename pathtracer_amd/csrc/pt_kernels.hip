@@ -30,33 +30,35 @@ namespace pt {
 __device__ __forceinline__ void test_object(float4 g0, float4 g1, float4 g2, int k, f3 o, f3 v,
                                             int last, int &best, float &best_t)
 {
-    const float num = fmaf(-o.z, g0.z, fmaf(-o.y, g0.y, fmaf(-o.x, g0.x, g0.w)));
+    // t = (A - o.n_raw) / (v.n_hat); every object operand is wave-uniform (SGPR)
+    const float on  = fmaf(o.z, g0.z, fmaf(o.y, g0.y, o.x * g0.x));
     const float den = fmaf(v.z, g1.z, fmaf(v.y, g1.y, v.x * g1.x));
-    const float t = num * __builtin_amdgcn_rcpf(den);
+    const float t = (g0.w - on) * __builtin_amdgcn_rcpf(den);
     // 0 < t < Inf (src/Object.hs:159), not the last-struck object
     // (src/Lib.hs:86-90), strictly closer than the best so far: an equal t
-    // keeps the earlier object, as Data.Vector.minimumBy does.
-    bool ok = (t > 0.0f) && (t < best_t) && (k != last);
+    // keeps the earlier object, as Data.Vector.minimumBy does.  Plain '&' so
+    // the lanes stay predicated instead of branching.
+    bool ok = (t > 0.0f) & (t < best_t) & (k != last);
     if (g1.w != __builtin_inff()) {          // wave-uniform: Disk (src/Object.hs:165-171)
         const float dx = fmaf(t, v.x, o.x) - g2.x;
         const float dy = fmaf(t, v.y, o.y) - g2.y;
         const float dz = fmaf(t, v.z, o.z) - g2.z;
-        ok = ok && (fmaf(dz, dz, fmaf(dy, dy, dx * dx)) < g1.w);
+        ok = ok & (fmaf(dz, dz, fmaf(dy, dy, dx * dx)) < g1.w);
     }
-    if (ok) { best = k; best_t = t; }
+    best = ok ? k : best;
+    best_t = ok ? t : best_t;
 }
 
 template <int NS>
-__device__ __forceinline__ void closest(const TraceArgs &a, const StaticGeom &sg, f3 o, f3 v,
+__device__ __forceinline__ void closest(const TraceArgs &a, const StaticGeom<NS> &sg, f3 o, f3 v,
                                         int last, int &best, float &best_t)
 {
     best = -1; best_t = __builtin_inff();
     if constexpr (NS > 0) {
+        // the host pads the list to NS with objects that can never be hit
 #pragma unroll
-        for (int k = 0; k < NS; ++k) {
-            if (k < a.n_obj)
-                test_object(sg.g[k][0], sg.g[k][1], sg.g[k][2], k, o, v, last, best, best_t);
-        }
+        for (int k = 0; k < NS; ++k)
+            test_object(sg.g[k][0], sg.g[k][1], sg.g[k][2], k, o, v, last, best, best_t);
     } else {
         const float4 *__restrict__ g = a.geom;
         for (int k = 0; k < a.n_obj; ++k)
@@ -70,13 +72,13 @@ __device__ __forceinline__ void closest(const TraceArgs &a, const StaticGeom &sg
 constexpr int TRACE_BLOCK = 256;
 
 template <int NS, bool REUSE, bool SPEC>
-__global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(TraceArgs a, StaticGeom sg)
+__global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(TraceArgs a, StaticGeom<NS> sg)
 {
     // Materials: LDS copy for small scenes (per-lane gather, <= 4 distinct
     // 64-B records land on distinct banks), global/L2 gather otherwise.
     __shared__ float4 s_mat[(NS > 0 ? NS : 1) * 4];
     if constexpr (NS > 0) {
-        if ((int)threadIdx.x < a.n_obj * 4) s_mat[threadIdx.x] = a.mat[threadIdx.x];
+        if ((int)threadIdx.x < min(a.n_obj, NS) * 4) s_mat[threadIdx.x] = a.mat[threadIdx.x];
         __syncthreads();
     }
     auto mat = [&](int k, int f) -> float4 {
@@ -201,9 +203,18 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(TraceArgs a, StaticG
 }
 
 template <int NS>
-static hipError_t launch_trace_ns(const TraceArgs &a, const StaticGeom &sg, bool reuse, bool spec,
+static hipError_t launch_trace_ns(const TraceArgs &a, const float4 *geom_host, bool reuse, bool spec,
                                   hipStream_t s)
 {
+    // pad the by-value object list to NS with records that never pass the
+    // 0 < t < Inf guard (n = 0 gives t = NaN)
+    StaticGeom<NS> sg;
+    for (int k = 0; k < (NS > 0 ? NS : 1); ++k) {
+        const bool real = NS > 0 && k < a.n_obj;
+        sg.g[k][0] = real ? geom_host[3 * k + 0] : make_float4(0.f, 0.f, 0.f, 0.f);
+        sg.g[k][1] = real ? geom_host[3 * k + 1] : make_float4(0.f, 0.f, 0.f, __builtin_inff());
+        sg.g[k][2] = real ? geom_host[3 * k + 2] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     const int npix = a.height * a.width;
     const dim3 grid((npix + TRACE_BLOCK - 1) / TRACE_BLOCK), block(TRACE_BLOCK);
     if (reuse) {
@@ -216,10 +227,11 @@ static hipError_t launch_trace_ns(const TraceArgs &a, const StaticGeom &sg, bool
     return hipGetLastError();
 }
 
-hipError_t launch_trace(const TraceArgs &a, const StaticGeom &sg, bool reuse, bool spec, hipStream_t s)
+hipError_t launch_trace(const TraceArgs &a, const float4 *geom_host, bool reuse, bool spec, hipStream_t s)
 {
-    if (a.n_obj <= MAX_STATIC_OBJECTS) return launch_trace_ns<MAX_STATIC_OBJECTS>(a, sg, reuse, spec, s);
-    return launch_trace_ns<0>(a, sg, reuse, spec, s);
+    if (a.n_obj <= 4) return launch_trace_ns<4>(a, geom_host, reuse, spec, s);
+    if (a.n_obj <= MAX_STATIC_OBJECTS) return launch_trace_ns<MAX_STATIC_OBJECTS>(a, geom_host, reuse, spec, s);
+    return launch_trace_ns<0>(a, geom_host, reuse, spec, s);
 }
 
 // ---------------------------------------------------------------------------
