@@ -95,8 +95,11 @@ def main():
         sys.exit("bench.py needs a GPU: libpt has no CPU path")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    # PT_BENCH_FORCE_DIST=1 drives the RCCL all-reduce path with a world of 1 (rehearsal on a 1-GPU box)
+    if world > 1 or os.environ.get("PT_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
+        if "MASTER_ADDR" not in os.environ:
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     my_spp, s_off, s_stride = shard_samples(args.spp, rank, world)

@@ -117,9 +117,9 @@ void flatten_object(const pt_object &ob, float4 *geom3, float4 *mat4, double *pr
                             {-st * len, 0.0, ct * len}};
     const float e = ob.emittance > 0.0 ? (float)ob.emittance : (ob.reflective ? -1.0f : 0.0f);
     mat4[0] = make_float4((float)ob.color[0], (float)ob.color[1], (float)ob.color[2], e);
-    mat4[1] = make_float4((float)M[0][0], (float)M[0][1], (float)M[0][2], (float)nh.x);
-    mat4[2] = make_float4((float)M[1][0], (float)M[1][1], (float)M[1][2], (float)nh.y);
-    mat4[3] = make_float4((float)M[2][0], (float)M[2][1], (float)M[2][2], (float)nh.z);
+    mat4[1] = make_float4((float)M[0][0], (float)M[0][1], (float)M[0][2], (float)M[1][0]);
+    mat4[2] = make_float4((float)M[1][1], (float)M[1][2], (float)M[2][0], (float)M[2][1]);
+    mat4[3] = make_float4((float)M[2][2], (float)nh.x, (float)nh.y, (float)nh.z);
 
     prim[0] = p.x; prim[1] = p.y; prim[2] = p.z;
     prim[3] = n.x; prim[4] = n.y; prim[5] = n.z;
@@ -170,7 +170,7 @@ int pt_create(pt_ctx **out, const pt_params *params)
     if (!out || !params) return fail(nullptr, PT_ERR_INVALID, "pt_create: null argument");
     *out = nullptr;
     const pt_params &p = *params;
-    if (p.height < 1 || p.width < 1 || (int64_t)p.height * p.width > ((int64_t)1 << 30))
+    if (p.height < 1 || p.width < 1 || (int64_t)p.height * p.width > ((int64_t)1 << 28))
         return fail(nullptr, PT_ERR_INVALID, "pt_create: height/width out of range");
     if (p.max_bounces < 1 || p.max_bounces > MAX_BOUNCES)
         return fail(nullptr, PT_ERR_LIMIT, "pt_create: max_bounces must be in 1..64");

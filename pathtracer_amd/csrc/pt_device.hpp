@@ -32,9 +32,11 @@ constexpr int GEOM_FLOATS = 12;
 // Material record, 16 floats (4 x float4), read with a per-lane index:
 //   m0 = (color.r, color.g, color.b, e)   e > 0: emittance (light)
 //                                         e = 0: diffuse, e = -1: reflective
-//   m1 = (M00, M01, M02, n_hat.x)         M = |n| * Rz(phi') * Ry(theta'),
-//   m2 = (M10, M11, M12, n_hat.y)         (theta', phi') = toSphericalCoords n
-//   m3 = (M20, M21, M22, n_hat.z)         (src/Util.hs:114-145)
+//   m1 = (M00, M01, M02, M10)             M = |n| * Rz(phi') * Ry(theta'),
+//   m2 = (M11, M12, M20, M21)             (theta', phi') = toSphericalCoords n
+//   m3 = (M22, n_hat.x, n_hat.y, n_hat.z) (src/Util.hs:114-145)
+// so a diffuse bounce reads m1, m2 (two 16-B LDS reads) and one dword of m3,
+// and only a specular bounce needs the unit normal.
 constexpr int MAT_FLOATS = 16;
 // fp64 record for the primary pass, 11 doubles:
 //   point[3], n_raw[3], n_hat[3] (normalize n, src/Triple.hs:66-69), radius, kind
@@ -88,12 +90,12 @@ constexpr float NOISE_REV = 40.0f / 360.0f;    // specular noise 40 degrees, src
 
 // diffuse (src/Lib.hs:129-132): rotateRel theta phi normal, with the rotation
 // about the (per-object constant) normal folded into M at upload.
-__device__ __forceinline__ f3 scatter_diffuse(float4 m1, float4 m2, float4 m3, float u1, float u2)
+__device__ __forceinline__ f3 scatter_diffuse(float4 m1, float4 m2, float m22, float u1, float u2)
 {
     const f3 l = local_dir(THETA_DIFFUSE_REV * u1, PHI_REV * u2);
     return mk3(fmaf(m1.z, l.z, fmaf(m1.y, l.y, m1.x * l.x)),
-               fmaf(m2.z, l.z, fmaf(m2.y, l.y, m2.x * l.x)),
-               fmaf(m3.z, l.z, fmaf(m3.y, l.y, m3.x * l.x)));
+               fmaf(m2.y, l.z, fmaf(m2.x, l.y, m1.w * l.x)),
+               fmaf(m22,  l.z, fmaf(m2.w, l.y, m2.z * l.x)));
 }
 
 // asin(x)/(2*pi) for x in [0,1], in revolutions.  Abramowitz-Stegun 4.4.46

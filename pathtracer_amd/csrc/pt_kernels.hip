@@ -74,16 +74,27 @@ constexpr int TRACE_BLOCK = 256;
 template <int NS, bool REUSE, bool SPEC>
 __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(TraceArgs a, StaticGeom<NS> sg)
 {
-    // Materials: LDS copy for small scenes (per-lane gather, <= 4 distinct
-    // 64-B records land on distinct banks), global/L2 gather otherwise.
-    __shared__ float4 s_mat[(NS > 0 ? NS : 1) * 4];
+    // Materials: LDS copy for small scenes, global/L2 gather otherwise.  The
+    // gather index differs per lane; records are spaced MAT_LDS_STRIDE = 5
+    // float4 (80 B) apart so that the same field of up to 8 different objects
+    // falls on 8 different 4-bank groups -- a 64-B spacing puts objects k and
+    // k+2 on the same banks (measured: 41 % of LDS cycles were conflicts).
+    constexpr int MAT_LDS_STRIDE = 5;
+    __shared__ float4 s_mat[(NS > 0 ? NS : 1) * MAT_LDS_STRIDE];
     if constexpr (NS > 0) {
-        if ((int)threadIdx.x < min(a.n_obj, NS) * 4) s_mat[threadIdx.x] = a.mat[threadIdx.x];
+        if ((int)threadIdx.x < min(a.n_obj, NS) * 4)
+            s_mat[(threadIdx.x >> 2) * MAT_LDS_STRIDE + (threadIdx.x & 3)] = a.mat[threadIdx.x];
         __syncthreads();
     }
     auto mat = [&](int k, int f) -> float4 {
-        if constexpr (NS > 0) return s_mat[k * 4 + f];
+        if constexpr (NS > 0) return s_mat[k * MAT_LDS_STRIDE + f];
         else                  return a.mat[k * 4 + f];
+    };
+    // The 9 matrix floats of a diffuse bounce.  (An inline-asm 2 x ds_read_b128 +
+    // ds_read_b32 form halves the LDS cycles but needs its own lgkmcnt wait,
+    // which measured 4 % slower than letting hipcc schedule these reads.)
+    auto mat_rot = [&](int k, float4 &m1, float4 &m2, float &m22) {
+        m1 = mat(k, 1); m2 = mat(k, 2); m22 = mat(k, 3).x;
     };
 
     const int npix = a.height * a.width;
@@ -98,7 +109,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(TraceArgs a, StaticG
     // traceCanvas adds onto the running sum (src/Lib.hs:65); continuing the
     // fp32 sum sample by sample makes k launches of 1 equal 1 launch of k.
     f3 acc = mk3(0.f, 0.f, 0.f);
-    if (in_canvas) acc = mk3(a.canvas[3 * pc + 0], a.canvas[3 * pc + 1], a.canvas[3 * pc + 2]);
+    if (in_canvas) acc = mk3(a.canvas[3 * (size_t)pc + 0], a.canvas[3 * (size_t)pc + 1], a.canvas[3 * (size_t)pc + 2]);
 
     // Primary segment: no jitter, no randomness (src/Lib.hs:41-51), so it is
     // computed once per pixel, in fp64, reference operation order.
@@ -135,12 +146,15 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(TraceArgs a, StaticG
         uint32_t r0, r1;
         philox2x32_10((uint32_t)pc, (gs << 6) | (uint32_t)bounce, a.seed, r0, r1);
         const float u1 = u24(r0), u2 = u24(r1);
-        const float4 m1 = mat(idx, 1), m2 = mat(idx, 2), m3 = mat(idx, 3);
         if constexpr (SPEC) {
-            if (e < 0.f)                                   // _reflective (src/Lib.hs:110)
-                return scatter_specular(din, mk3(m1.w, m2.w, m3.w), u1, u2, NOISE_REV);
+            if (e < 0.f) {                                 // _reflective (src/Lib.hs:110)
+                const float4 m3 = mat(idx, 3);
+                return scatter_specular(din, mk3(m3.y, m3.z, m3.w), u1, u2, NOISE_REV);
+            }
         }
-        return scatter_diffuse(m1, m2, m3, u1, u2);        // src/Lib.hs:111
+        float4 m1, m2; float m22;
+        mat_rot(idx, m1, m2, m22);
+        return scatter_diffuse(m1, m2, m22, u1, u2);                               // src/Lib.hs:111
     };
 
     if constexpr (REUSE) {
@@ -193,7 +207,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(TraceArgs a, StaticG
     }
 
     if (in_canvas) {
-        a.canvas[3 * pc + 0] = acc.x; a.canvas[3 * pc + 1] = acc.y; a.canvas[3 * pc + 2] = acc.z;
+        a.canvas[3 * (size_t)pc + 0] = acc.x; a.canvas[3 * (size_t)pc + 1] = acc.y; a.canvas[3 * (size_t)pc + 2] = acc.z;
     }
 
     // one 64-bit atomic per wave for the segment counter
@@ -321,7 +335,7 @@ __global__ void dev_diffuse_kernel(int n, const float4 *__restrict__ m, const fl
 {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
-    const f3 r = scatter_diffuse(m[4 * k + 1], m[4 * k + 2], m[4 * k + 3], u[2 * k], u[2 * k + 1]);
+    const f3 r = scatter_diffuse(m[4 * k + 1], m[4 * k + 2], m[4 * k + 3].x, u[2 * k], u[2 * k + 1]);
     out[3 * k] = r.x; out[3 * k + 1] = r.y; out[3 * k + 2] = r.z;
 }
 

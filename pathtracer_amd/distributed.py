@@ -27,7 +27,7 @@ def allreduce_canvas(canvas, group=None):
     """In-place sum of the radiance canvas over all ranks (torch tensor on the
     rank's GPU for the nccl(=RCCL) backend, CPU tensor under gloo)."""
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_available() and dist.is_initialized():
         dist.all_reduce(canvas, op=dist.ReduceOp.SUM, group=group)
     return canvas
 
