@@ -61,7 +61,8 @@ __device__ __forceinline__ void philox2x32_10(uint32_t c0, uint32_t c1, uint32_t
     for (int r = 0; r < 10; ++r) {
         const uint64_t prod = (uint64_t)0xD256D193u * (uint64_t)c0;
         const uint32_t hi = (uint32_t)(prod >> 32), lo = (uint32_t)prod;
-        c0 = hi ^ (key + (uint32_t)r * 0x9E3779B9u) ^ c1;
+        // three-input xor in one VALU op (v_bitop3_b32, truth table 0x96)
+        c0 = __builtin_amdgcn_bitop3_b32(hi, key + (uint32_t)r * 0x9E3779B9u, c1, 0x96);
         c1 = lo;
     }
     o0 = c0; o1 = c1;
@@ -70,6 +71,9 @@ __device__ __forceinline__ void philox2x32_10(uint32_t c0, uint32_t c1, uint32_t
 // 24-bit uniform in [0,1): exactly representable in fp32 and fp64, so the
 // device and the oracle's Philox mode see the same number.
 __device__ __forceinline__ float u24(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }
+// u24(x) * scale with the two multiplies folded into one: 2^-24 is a power of
+// two, so (k * 2^-24) * c and k * (c * 2^-24) round identically.
+__device__ __forceinline__ float u24_scaled(uint32_t x, float scale) { return (float)(x >> 8) * (scale * (1.0f / 16777216.0f)); }
 
 // sin/cos of an angle given in REVOLUTIONS (v_sin_f32 / v_cos_f32 take the
 // argument pre-divided by 2*pi; |x| <= 256).
@@ -93,6 +97,15 @@ constexpr float NOISE_REV = 40.0f / 360.0f;    // specular noise 40 degrees, src
 __device__ __forceinline__ f3 scatter_diffuse(float4 m1, float4 m2, float m22, float u1, float u2)
 {
     const f3 l = local_dir(THETA_DIFFUSE_REV * u1, PHI_REV * u2);
+    return mk3(fmaf(m1.z, l.z, fmaf(m1.y, l.y, m1.x * l.x)),
+               fmaf(m2.y, l.z, fmaf(m2.x, l.y, m1.w * l.x)),
+               fmaf(m22,  l.z, fmaf(m2.w, l.y, m2.z * l.x)));
+}
+
+// The trace kernel's form: the two Philox words go straight to angles.
+__device__ __forceinline__ f3 scatter_diffuse_bits(float4 m1, float4 m2, float m22, uint32_t r0, uint32_t r1)
+{
+    const f3 l = local_dir(u24_scaled(r0, THETA_DIFFUSE_REV), u24_scaled(r1, PHI_REV));
     return mk3(fmaf(m1.z, l.z, fmaf(m1.y, l.y, m1.x * l.x)),
                fmaf(m2.y, l.z, fmaf(m2.x, l.y, m1.w * l.x)),
                fmaf(m22,  l.z, fmaf(m2.w, l.y, m2.z * l.x)));

@@ -87,7 +87,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(TraceArgs a, StaticG
         __syncthreads();
     }
     auto mat = [&](int k, int f) -> float4 {
-        if constexpr (NS > 0) return s_mat[k * MAT_LDS_STRIDE + f];
+        if constexpr (NS > 0) return s_mat[__mul24(k, MAT_LDS_STRIDE) + f];
         else                  return a.mat[k * 4 + f];
     };
     // The 9 matrix floats of a diffuse bounce.  (An inline-asm 2 x ds_read_b128 +
@@ -145,16 +145,15 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(TraceArgs a, StaticG
     auto scatter = [&](int idx, float e, f3 din, int bounce) -> f3 {
         uint32_t r0, r1;
         philox2x32_10((uint32_t)pc, (gs << 6) | (uint32_t)bounce, a.seed, r0, r1);
-        const float u1 = u24(r0), u2 = u24(r1);
         if constexpr (SPEC) {
             if (e < 0.f) {                                 // _reflective (src/Lib.hs:110)
                 const float4 m3 = mat(idx, 3);
-                return scatter_specular(din, mk3(m3.y, m3.z, m3.w), u1, u2, NOISE_REV);
+                return scatter_specular(din, mk3(m3.y, m3.z, m3.w), u24(r0), u24(r1), NOISE_REV);
             }
         }
         float4 m1, m2; float m22;
         mat_rot(idx, m1, m2, m22);
-        return scatter_diffuse(m1, m2, m22, u1, u2);                               // src/Lib.hs:111
+        return scatter_diffuse_bits(m1, m2, m22, r0, r1);                          // src/Lib.hs:111
     };
 
     if constexpr (REUSE) {
