@@ -78,6 +78,9 @@ typedef struct {
  * per-pixel fp64 primary hit (the primary ray has no jitter, src/Lib.hs:41-51,
  * so the hit is the same for every sample of a pixel). */
 #define PT_FLAG_NO_PRIMARY_REUSE 1
+/* Scenes of more than 8 objects: read the object list through scalar loads
+ * from L2 instead of staging it in LDS tiles (kept for A/B measurement). */
+#define PT_FLAG_SCALAR_STREAM 2
 
 typedef struct pt_ctx pt_ctx;
 

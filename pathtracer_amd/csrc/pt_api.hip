@@ -290,7 +290,8 @@ int pt_trace(pt_ctx *c, int32_t iters)
         a.sample_begin = (uint32_t)(c->p.sample_offset + c->samples_done * c->p.sample_stride);
         a.sample_stride = (uint32_t)c->p.sample_stride;
         a.n_samples = n;
-        PT_HIP(c, launch_trace(a, c->h_geom.data(), reuse, c->has_specular, c->stream));
+        PT_HIP(c, launch_trace(a, c->h_geom.data(), reuse, c->has_specular,
+                               (c->p.flags & PT_FLAG_SCALAR_STREAM) != 0, c->stream));
         c->samples_done += n;
         left -= n;
         ++launches;

@@ -31,11 +31,12 @@ struct TraceArgs {
     uint32_t sample_begin;             // global index of this launch's first sample
     uint32_t sample_stride;
     int      n_samples;                // samples per pixel in this launch
+    int      tile_objs;                // objects per LDS tile (tiled kernel; set by the launcher)
 };
 
 // Launchers (pt_kernels.hip).  All return the hipError_t of the launch.
 hipError_t launch_trace(const TraceArgs &a, const float4 *geom_host, bool reuse_primary,
-                        bool has_specular, hipStream_t s);
+                        bool has_specular, bool scalar_stream, hipStream_t s);
 hipError_t launch_primary(const double *prim, int n_obj, int H, int W, double camera_depth,
                           int32_t *idx, double *t, double *normal, hipStream_t s);
 hipError_t launch_rgb8(const float *canvas, uint8_t *rgb, int H, int W, int mode,

@@ -49,20 +49,64 @@ __device__ __forceinline__ void test_object(float4 g0, float4 g1, float4 g2, int
     best_t = ok ? t : best_t;
 }
 
+// LDS tile of geometry records for the tiled kernel (NS == -1), dynamic size.
+extern __shared__ float4 s_tile[];
+
 template <int NS>
 __device__ __forceinline__ void closest(const TraceArgs &a, const StaticGeom<NS> &sg, f3 o, f3 v,
                                         int last, int &best, float &best_t)
 {
     best = -1; best_t = __builtin_inff();
+    if constexpr (NS == -1) {
+        // Object list staged in LDS per workgroup.  A scene that fits one tile
+        // was staged once at kernel start and the waves run free; a larger one
+        // streams tile after tile from HBM/L2 with the whole workgroup in
+        // lockstep (the caller's loop is block-uniform in that case).  Every
+        // lane reads the SAME record: an LDS broadcast, conflict-free.
+        const int n = a.n_obj, T = a.tile_objs;
+        for (int base = 0; base < n; base += T) {
+            const int cnt = min(T, n - base);
+            if (n > T) {
+                __syncthreads();                            // everyone is done with the previous tile
+                for (int i = threadIdx.x; i < cnt * 3; i += blockDim.x) s_tile[i] = a.geom[(size_t)base * 3 + i];
+                __syncthreads();
+            }
+#pragma unroll 2
+            for (int k = 0; k < cnt; ++k)
+                test_object(s_tile[3 * k + 0], s_tile[3 * k + 1], s_tile[3 * k + 2], base + k, o, v, last, best,
+                            best_t);
+        }
+        return;
+    }
     if constexpr (NS > 0) {
         // the host pads the list to NS with objects that can never be hit
 #pragma unroll
         for (int k = 0; k < NS; ++k)
             test_object(sg.g[k][0], sg.g[k][1], sg.g[k][2], k, o, v, last, best, best_t);
     } else {
+        // Large scenes: the records stream through the scalar cache from L2/HBM.
+        // Scalar loads return out of order, so the only safe wait is
+        // lgkmcnt(0); the loop is therefore double-buffered by hand -- the
+        // loads of objects k+2, k+3 are issued right after the wait that
+        // retires k, k+1 and land while the VALU works on k, k+1.
         const float4 *__restrict__ g = a.geom;
-        for (int k = 0; k < a.n_obj; ++k)
-            test_object(g[3 * k + 0], g[3 * k + 1], g[3 * k + 2], k, o, v, last, best, best_t);
+        const int n = a.n_obj;
+        auto load = [&](float4 (&r)[3], int k) {
+            const int kk = k < n ? k : n - 1;              // clamped: a tail slot re-reads the last object
+            r[0] = g[3 * kk + 0]; r[1] = g[3 * kk + 1]; r[2] = g[3 * kk + 2];
+        };
+        float4 A0[3], A1[3], B0[3], B1[3];
+        load(A0, 0); load(A1, 1);
+        for (int k = 0; k < n; k += 4) {
+            load(B0, k + 2); load(B1, k + 3);
+            __builtin_amdgcn_sched_barrier(0);             // keep the prefetch ahead of the arithmetic
+            test_object(A0[0], A0[1], A0[2], k, o, v, last, best, best_t);
+            if (k + 1 < n) test_object(A1[0], A1[1], A1[2], k + 1, o, v, last, best, best_t);
+            load(A0, k + 4); load(A1, k + 5);
+            __builtin_amdgcn_sched_barrier(0);
+            if (k + 2 < n) test_object(B0[0], B0[1], B0[2], k + 2, o, v, last, best, best_t);
+            if (k + 3 < n) test_object(B1[0], B1[1], B1[2], k + 3, o, v, last, best, best_t);
+        }
     }
 }
 
@@ -71,9 +115,21 @@ __device__ __forceinline__ void closest(const TraceArgs &a, const StaticGeom<NS>
 // ---------------------------------------------------------------------------
 constexpr int TRACE_BLOCK = 256;
 
+constexpr int TILED_BLOCK = 512;
+constexpr int TILE_OBJECTS = 1024;     // 48 KB of LDS per workgroup: 3 workgroups (24 waves) per CU
+
 template <int NS, bool REUSE, bool SPEC>
-__global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(TraceArgs a, StaticGeom<NS> sg)
+__global__ __launch_bounds__(NS == -1 ? TILED_BLOCK : TRACE_BLOCK) void trace_kernel(TraceArgs a, StaticGeom<NS> sg)
 {
+    constexpr int BLOCK = NS == -1 ? TILED_BLOCK : TRACE_BLOCK;
+    bool lockstep = false;
+    if constexpr (NS == -1) {
+        lockstep = a.n_obj > a.tile_objs;
+        if (!lockstep) {                                    // the whole scene fits one tile: stage it once
+            for (int i = threadIdx.x; i < a.n_obj * 3; i += BLOCK) s_tile[i] = a.geom[i];
+            __syncthreads();
+        }
+    }
     // Materials: LDS copy for small scenes, global/L2 gather otherwise.  The
     // gather index differs per lane; records are spaced MAT_LDS_STRIDE = 5
     // float4 (80 B) apart so that the same field of up to 8 different objects
@@ -98,7 +154,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(TraceArgs a, StaticG
     };
 
     const int npix = a.height * a.width;
-    const int pixel = blockIdx.x * TRACE_BLOCK + threadIdx.x;
+    const int pixel = blockIdx.x * BLOCK + threadIdx.x;
     const bool in_canvas = pixel < npix;
     const int pc = in_canvas ? pixel : 0;
     const int pi = pc / a.width, pj = pc - pi * a.width;
@@ -163,13 +219,20 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(TraceArgs a, StaticG
         }
     }
 
-    while (s < n_my) {
+    for (;;) {
+        const bool alive = s < n_my;
+        if constexpr (NS == -1) {
+            // streamed tiles need every wave of the workgroup at the barriers
+            if (lockstep ? !__syncthreads_or(alive) : !alive) break;
+        } else {
+            if (!alive) break;
+        }
         int k; float t;
         closest<NS>(a, sg, o, d, last, k, t);
-        segs += 1;
+        segs += alive ? 1 : 0;
         const bool hit = k >= 0;
         const float4 m0 = mat(hit ? k : 0, 0);
-        const bool emissive = hit && (m0.w > 0.f);
+        const bool emissive = hit && (m0.w > 0.f) && alive;
         // after this search b+1 have run; terminalColor 0 ends the path black
         const bool terminal = !hit || emissive || (b + 1 >= B);
         if (emissive) {                                    // emittance * pixel (src/Lib.hs:74)
@@ -216,8 +279,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(TraceArgs a, StaticG
 }
 
 template <int NS>
-static hipError_t launch_trace_ns(const TraceArgs &a, const float4 *geom_host, bool reuse, bool spec,
-                                  hipStream_t s)
+static hipError_t launch_trace_ns(TraceArgs a, const float4 *geom_host, bool reuse, bool spec, hipStream_t s)
 {
     // pad the by-value object list to NS with records that never pass the
     // 0 < t < Inf guard (n = 0 gives t = NaN)
@@ -228,23 +290,31 @@ static hipError_t launch_trace_ns(const TraceArgs &a, const float4 *geom_host, b
         sg.g[k][1] = real ? geom_host[3 * k + 1] : make_float4(0.f, 0.f, 0.f, __builtin_inff());
         sg.g[k][2] = real ? geom_host[3 * k + 2] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    constexpr int BLOCK = NS == -1 ? TILED_BLOCK : TRACE_BLOCK;
+    size_t smem = 0;
+    if (NS == -1) {
+        a.tile_objs = a.n_obj < TILE_OBJECTS ? a.n_obj : TILE_OBJECTS;
+        smem = (size_t)a.tile_objs * 3 * sizeof(float4);
+    }
     const int npix = a.height * a.width;
-    const dim3 grid((npix + TRACE_BLOCK - 1) / TRACE_BLOCK), block(TRACE_BLOCK);
+    const dim3 grid((npix + BLOCK - 1) / BLOCK), block(BLOCK);
     if (reuse) {
-        if (spec) hipLaunchKernelGGL((trace_kernel<NS, true, true>), grid, block, 0, s, a, sg);
-        else      hipLaunchKernelGGL((trace_kernel<NS, true, false>), grid, block, 0, s, a, sg);
+        if (spec) hipLaunchKernelGGL((trace_kernel<NS, true, true>), grid, block, smem, s, a, sg);
+        else      hipLaunchKernelGGL((trace_kernel<NS, true, false>), grid, block, smem, s, a, sg);
     } else {
-        if (spec) hipLaunchKernelGGL((trace_kernel<NS, false, true>), grid, block, 0, s, a, sg);
-        else      hipLaunchKernelGGL((trace_kernel<NS, false, false>), grid, block, 0, s, a, sg);
+        if (spec) hipLaunchKernelGGL((trace_kernel<NS, false, true>), grid, block, smem, s, a, sg);
+        else      hipLaunchKernelGGL((trace_kernel<NS, false, false>), grid, block, smem, s, a, sg);
     }
     return hipGetLastError();
 }
 
-hipError_t launch_trace(const TraceArgs &a, const float4 *geom_host, bool reuse, bool spec, hipStream_t s)
+hipError_t launch_trace(const TraceArgs &a, const float4 *geom_host, bool reuse, bool spec, bool scalar_stream,
+                        hipStream_t s)
 {
     if (a.n_obj <= 4) return launch_trace_ns<4>(a, geom_host, reuse, spec, s);
     if (a.n_obj <= MAX_STATIC_OBJECTS) return launch_trace_ns<MAX_STATIC_OBJECTS>(a, geom_host, reuse, spec, s);
-    return launch_trace_ns<0>(a, geom_host, reuse, spec, s);
+    if (scalar_stream) return launch_trace_ns<0>(a, geom_host, reuse, spec, s);
+    return launch_trace_ns<-1>(a, geom_host, reuse, spec, s);
 }
 
 // ---------------------------------------------------------------------------

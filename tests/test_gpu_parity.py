@@ -195,12 +195,20 @@ def test_pathwise_parity_same_stream(pa, H, W, spp, bounces, flags):
     assert abs(segs - expect) <= 0.002 * expect
 
 
-@pytest.mark.parametrize("n,seed,bounces", [(6, 5, 6), (8, 6, 8), (40, 7, 6), (300, 8, 5)])
-def test_pathwise_parity_random_disks(pa, n, seed, bounces):
-    """Diffuse + specular mix, static (n <= 8) and dynamic object loops."""
+@pytest.mark.parametrize("flags", [0, 2])
+@pytest.mark.parametrize("n,seed,bounces", [(6, 5, 6), (8, 6, 8), (40, 7, 6), (300, 8, 5), (1024, 9, 4),
+                                            (1025, 10, 4), (2500, 11, 3)])
+def test_pathwise_parity_random_disks(pa, n, seed, bounces, flags):
+    """Diffuse + specular mix through every object-list path: by-value SGPR list
+    (n <= 8), one LDS tile (n <= 1024), LDS tiles streamed in workgroup lockstep
+    (n > 1024), and the scalar-load stream (flags = PT_FLAG_SCALAR_STREAM)."""
+    if flags and n <= 8:
+        pytest.skip("small scenes never take the streamed paths")
     objs = pa.random_disk_scene(n, seed)
     H, W, spp = 40, 56, 6
-    with pa.Renderer(pa.Params(H, W, 60.0, spp, bounces), objs, seed=3) as r:
+    if n > 1000:
+        H, W, spp = 24, 40, 3
+    with pa.Renderer(pa.Params(H, W, 60.0, spp, bounces), objs, seed=3, flags=flags) as r:
         r.trace(spp)
         dev = r.read_sum()
     tr = O.Tracer(O.params(H, W, 60.0, bounces, O.PHILOX, 3), O.scene_from(objs))
