@@ -78,9 +78,11 @@ typedef struct {
  * per-pixel fp64 primary hit (the primary ray has no jitter, src/Lib.hs:41-51,
  * so the hit is the same for every sample of a pixel). */
 #define PT_FLAG_NO_PRIMARY_REUSE 1
-/* Scenes of more than 8 objects: read the object list through scalar loads
- * from L2 instead of staging it in LDS tiles (kept for A/B measurement). */
-#define PT_FLAG_SCALAR_STREAM 2
+/* Scenes of more than 8 objects: stage the object list in LDS tiles per
+ * workgroup (streamed in lockstep beyond 1,024 objects) instead of streaming
+ * it through scalar loads from L2.  Measured 5-12 % slower on MI355X
+ * (DESIGN.md 3.1), so it is the option, not the default. */
+#define PT_FLAG_LDS_TILES 2
 
 typedef struct pt_ctx pt_ctx;
 

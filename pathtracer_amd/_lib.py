@@ -15,7 +15,7 @@ PT_ERR_INVALID, PT_ERR_NO_DEVICE, PT_ERR_HIP, PT_ERR_NO_SCENE, PT_ERR_LIMIT = -1
 PT_INFINITE_PLANE, PT_DISK = 0, 1
 PT_RGB8_REFERENCE, PT_RGB8_MEAN_CLAMP, PT_RGB8_MEAN_GAMMA = 0, 1, 2
 PT_FLAG_NO_PRIMARY_REUSE = 1
-PT_FLAG_SCALAR_STREAM = 2
+PT_FLAG_LDS_TILES = 2
 
 
 class pt_object(C.Structure):

@@ -240,7 +240,15 @@ int pt_scene_upload(pt_ctx *c, const pt_object *objs, int32_t n)
         if (objs[k].kind != PT_INFINITE_PLANE && objs[k].kind != PT_DISK)
             return fail(c, PT_ERR_INVALID, "pt_scene_upload: unknown Form kind");
 
-    std::vector<float4> geom((size_t)n * 3), mat((size_t)n * 4);
+    // 8 trailing records that can never be hit (n = 0 gives t = NaN): the
+    // streamed closest-hit loop works in groups of 4 and prefetches one group ahead
+    constexpr int GEOM_PAD = 8;
+    std::vector<float4> geom((size_t)(n + GEOM_PAD) * 3), mat((size_t)n * 4);
+    for (int k = n; k < n + GEOM_PAD; ++k) {
+        geom[(size_t)k * 3 + 0] = make_float4(0.f, 0.f, 0.f, 0.f);
+        geom[(size_t)k * 3 + 1] = make_float4(0.f, 0.f, 0.f, std::numeric_limits<float>::infinity());
+        geom[(size_t)k * 3 + 2] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     std::vector<double> prim((size_t)n * PRIM_DOUBLES);
     bool spec = false;
     for (int k = 0; k < n; ++k) {
@@ -291,7 +299,7 @@ int pt_trace(pt_ctx *c, int32_t iters)
         a.sample_stride = (uint32_t)c->p.sample_stride;
         a.n_samples = n;
         PT_HIP(c, launch_trace(a, c->h_geom.data(), reuse, c->has_specular,
-                               (c->p.flags & PT_FLAG_SCALAR_STREAM) != 0, c->stream));
+                               (c->p.flags & PT_FLAG_LDS_TILES) != 0, c->stream));
         c->samples_done += n;
         left -= n;
         ++launches;

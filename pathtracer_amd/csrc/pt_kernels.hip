@@ -49,6 +49,44 @@ __device__ __forceinline__ void test_object(float4 g0, float4 g1, float4 g2, int
     best_t = ok ? t : best_t;
 }
 
+// Streamed object lists (more than 8 objects) run thousands of tests per
+// segment, and there the lane-mask bookkeeping of test_object (s_and/s_or on
+// SGPR pairs, ~20 SALU per object) saturates the CU's single scalar unit before
+// the four SIMDs are busy.  test_object_key keeps every decision in VGPRs:
+// the candidate is the ordered integer key bits(t) - 1, so that
+//   t <= -0, NaN, +Inf  ->  key >= 0x7f7fffff  (never accepted),
+//   t == +0             ->  key == 0xffffffff  (0 < t is strict, src/Object.hs:159),
+// and "closer" is one unsigned compare; a strict '<' keeps the earlier object
+// on ties as minimumBy does.
+constexpr uint32_t KEY_INVALID = 0xffffffffu;
+constexpr uint32_t KEY_LIMIT   = 0x7f7fffffu;   // bits(+Inf) - 1: keys below are finite positive t
+
+__device__ __forceinline__ void test_object_key(float4 g0, float4 g1, float4 g2, int k, f3 o, f3 v,
+                                                int last, int &best, uint32_t &best_key)
+{
+    const float on  = fmaf(o.z, g0.z, fmaf(o.y, g0.y, o.x * g0.x));
+    const float den = fmaf(v.z, g1.z, fmaf(v.y, g1.y, v.x * g1.x));
+    const float t = (g0.w - on) * __builtin_amdgcn_rcpf(den);
+    uint32_t key = __float_as_uint(t) - 1u;
+    key = (k == last) ? KEY_INVALID : key;                // _lastStruck (src/Lib.hs:86-90)
+    if (g1.w != __builtin_inff()) {                       // wave-uniform: Disk (src/Object.hs:165-171)
+        const float dx = fmaf(t, v.x, o.x) - g2.x;
+        const float dy = fmaf(t, v.y, o.y) - g2.y;
+        const float dz = fmaf(t, v.z, o.z) - g2.z;
+        key = (fmaf(dz, dz, fmaf(dy, dy, dx * dx)) < g1.w) ? key : KEY_INVALID;
+    }
+    const bool better = key < best_key;
+    best = better ? k : best;
+    best_key = better ? key : best_key;
+}
+
+__device__ __forceinline__ void key_result(int &best, uint32_t best_key, float &best_t)
+{
+    const bool hit = best_key < KEY_LIMIT;
+    best = hit ? best : -1;
+    best_t = __uint_as_float(best_key + 1u);
+}
+
 // LDS tile of geometry records for the tiled kernel (NS == -1), dynamic size.
 extern __shared__ float4 s_tile[];
 
@@ -57,6 +95,7 @@ __device__ __forceinline__ void closest(const TraceArgs &a, const StaticGeom<NS>
                                         int last, int &best, float &best_t)
 {
     best = -1; best_t = __builtin_inff();
+    uint32_t best_key = KEY_LIMIT;
     if constexpr (NS == -1) {
         // Object list staged in LDS per workgroup.  A scene that fits one tile
         // was staged once at kernel start and the waves run free; a larger one
@@ -73,9 +112,10 @@ __device__ __forceinline__ void closest(const TraceArgs &a, const StaticGeom<NS>
             }
 #pragma unroll 2
             for (int k = 0; k < cnt; ++k)
-                test_object(s_tile[3 * k + 0], s_tile[3 * k + 1], s_tile[3 * k + 2], base + k, o, v, last, best,
-                            best_t);
+                test_object_key(s_tile[3 * k + 0], s_tile[3 * k + 1], s_tile[3 * k + 2], base + k, o, v, last, best,
+                                best_key);
         }
+        key_result(best, best_key, best_t);
         return;
     }
     if constexpr (NS > 0) {
@@ -89,24 +129,25 @@ __device__ __forceinline__ void closest(const TraceArgs &a, const StaticGeom<NS>
         // lgkmcnt(0); the loop is therefore double-buffered by hand -- the
         // loads of objects k+2, k+3 are issued right after the wait that
         // retires k, k+1 and land while the VALU works on k, k+1.
+        // (the host pads the list with 4 never-hit records, so the prefetch
+        // needs no bounds logic: one pointer bump per pair)
         const float4 *__restrict__ g = a.geom;
         const int n = a.n_obj;
-        auto load = [&](float4 (&r)[3], int k) {
-            const int kk = k < n ? k : n - 1;              // clamped: a tail slot re-reads the last object
-            r[0] = g[3 * kk + 0]; r[1] = g[3 * kk + 1]; r[2] = g[3 * kk + 2];
-        };
         float4 A0[3], A1[3], B0[3], B1[3];
-        load(A0, 0); load(A1, 1);
+        auto load = [&](float4 (&r)[3], const float4 *q) { r[0] = q[0]; r[1] = q[1]; r[2] = q[2]; };
+        load(A0, g); load(A1, g + 3);
         for (int k = 0; k < n; k += 4) {
-            load(B0, k + 2); load(B1, k + 3);
+            load(B0, g + 6); load(B1, g + 9);
             __builtin_amdgcn_sched_barrier(0);             // keep the prefetch ahead of the arithmetic
-            test_object(A0[0], A0[1], A0[2], k, o, v, last, best, best_t);
-            if (k + 1 < n) test_object(A1[0], A1[1], A1[2], k + 1, o, v, last, best, best_t);
-            load(A0, k + 4); load(A1, k + 5);
+            test_object_key(A0[0], A0[1], A0[2], k, o, v, last, best, best_key);
+            test_object_key(A1[0], A1[1], A1[2], k + 1, o, v, last, best, best_key);
+            g += 12;
+            load(A0, g); load(A1, g + 3);
             __builtin_amdgcn_sched_barrier(0);
-            if (k + 2 < n) test_object(B0[0], B0[1], B0[2], k + 2, o, v, last, best, best_t);
-            if (k + 3 < n) test_object(B1[0], B1[1], B1[2], k + 3, o, v, last, best, best_t);
+            test_object_key(B0[0], B0[1], B0[2], k + 2, o, v, last, best, best_key);
+            test_object_key(B1[0], B1[1], B1[2], k + 3, o, v, last, best, best_key);
         }
+        key_result(best, best_key, best_t);
     }
 }
 
@@ -308,13 +349,13 @@ static hipError_t launch_trace_ns(TraceArgs a, const float4 *geom_host, bool reu
     return hipGetLastError();
 }
 
-hipError_t launch_trace(const TraceArgs &a, const float4 *geom_host, bool reuse, bool spec, bool scalar_stream,
+hipError_t launch_trace(const TraceArgs &a, const float4 *geom_host, bool reuse, bool spec, bool lds_tiles,
                         hipStream_t s)
 {
     if (a.n_obj <= 4) return launch_trace_ns<4>(a, geom_host, reuse, spec, s);
     if (a.n_obj <= MAX_STATIC_OBJECTS) return launch_trace_ns<MAX_STATIC_OBJECTS>(a, geom_host, reuse, spec, s);
-    if (scalar_stream) return launch_trace_ns<0>(a, geom_host, reuse, spec, s);
-    return launch_trace_ns<-1>(a, geom_host, reuse, spec, s);
+    if (lds_tiles) return launch_trace_ns<-1>(a, geom_host, reuse, spec, s);
+    return launch_trace_ns<0>(a, geom_host, reuse, spec, s);
 }
 
 // ---------------------------------------------------------------------------

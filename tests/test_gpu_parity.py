@@ -201,7 +201,7 @@ def test_pathwise_parity_same_stream(pa, H, W, spp, bounces, flags):
 def test_pathwise_parity_random_disks(pa, n, seed, bounces, flags):
     """Diffuse + specular mix through every object-list path: by-value SGPR list
     (n <= 8), one LDS tile (n <= 1024), LDS tiles streamed in workgroup lockstep
-    (n > 1024), and the scalar-load stream (flags = PT_FLAG_SCALAR_STREAM)."""
+    (n > 1024), scalar-load stream from L2 by default; flags = PT_FLAG_LDS_TILES stages the list in LDS."""
     if flags and n <= 8:
         pytest.skip("small scenes never take the streamed paths")
     objs = pa.random_disk_scene(n, seed)

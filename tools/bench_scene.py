@@ -20,7 +20,7 @@ ap.add_argument("--flags", type=int, default=0)
 args = ap.parse_args()
 for n in args.n:
     objs = pa.random_disk_scene(n, 1 if n <= 1000 else 2)
-    spp = max(1, args.spp * 100 // max(n, 100))
+    spp = args.spp
     with pa.Renderer(pa.Params(args.height, args.width, 500.0, spp, args.bounces), objs, seed=1, flags=args.flags) as r:
         r.set_timing(True)
         r.trace(spp)
