@@ -77,6 +77,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--no-primary-reuse", action="store_true")
+    ap.add_argument("--no-steal", action="store_true", help="PT_FLAG_NO_STEAL: strict per-lane sample order")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -104,7 +105,7 @@ def main():
 
     my_spp, s_off, s_stride = shard_samples(args.spp, rank, world)
     P = pa.Params(args.height, args.width, args.camera_depth, args.spp, args.bounces)
-    flags = pa.PT_FLAG_NO_PRIMARY_REUSE if args.no_primary_reuse else 0
+    flags = (pa.PT_FLAG_NO_PRIMARY_REUSE if args.no_primary_reuse else 0) | (pa.PT_FLAG_NO_STEAL if args.no_steal else 0)
     r = pa.Renderer(P, pa.objects, seed=0, device=local_rank, sample_offset=s_off, sample_stride=s_stride,
                     flags=flags)
     stream = torch.cuda.current_stream()

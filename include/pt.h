@@ -83,6 +83,12 @@ typedef struct {
  * it through scalar loads from L2.  Measured 5-12 % slower on MI355X
  * (DESIGN.md 3.1), so it is the option, not the default. */
 #define PT_FLAG_LDS_TILES 2
+/* Keep every lane on its own pixel for the whole launch (no wave-level work
+ * sharing): a pixel's samples are then summed strictly in sample order, which
+ * makes k calls of pt_trace(1) equal one call of pt_trace(k) bit for bit.  By
+ * default idle lanes help other pixels of their wave and the two differ by
+ * fp32 rounding of the per-pixel sum. */
+#define PT_FLAG_NO_STEAL 4
 
 typedef struct pt_ctx pt_ctx;
 
@@ -103,7 +109,8 @@ int pt_scene_upload(pt_ctx *ctx, const pt_object *objs, int32_t n);
 
 /* `iters` applications of traceCanvas (src/Lib.hs:58-65): adds `iters` more
  * samples per pixel to the device canvas.  Sample indices continue from the
- * running count, so k calls of 1 equal one call of k bit for bit.  Returns
+ * running count, so k calls of 1 render the same paths as one call of k (equal
+ * up to fp32 summation order; bit for bit under PT_FLAG_NO_STEAL).  Returns
  * after the work is queued on the context's stream. */
 int pt_trace(pt_ctx *ctx, int32_t iters);
 

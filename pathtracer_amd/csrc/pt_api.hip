@@ -299,7 +299,8 @@ int pt_trace(pt_ctx *c, int32_t iters)
         a.sample_stride = (uint32_t)c->p.sample_stride;
         a.n_samples = n;
         PT_HIP(c, launch_trace(a, c->h_geom.data(), reuse, c->has_specular,
-                               (c->p.flags & PT_FLAG_LDS_TILES) != 0, c->stream));
+                               (c->p.flags & PT_FLAG_LDS_TILES) != 0,
+                               (c->p.flags & PT_FLAG_NO_STEAL) == 0, c->stream));
         c->samples_done += n;
         left -= n;
         ++launches;

@@ -68,6 +68,23 @@ __device__ __forceinline__ void philox2x32_10(uint32_t c0, uint32_t c1, uint32_t
     o0 = c0; o1 = c1;
 }
 
+// The same generator with the first round's product M * c0 supplied by the
+// caller: the trace kernel's c0 is the pixel index, constant for as long as a
+// lane works on one pixel, so that multiply leaves the per-segment loop.
+__device__ __forceinline__ void philox2x32_10_pre(uint32_t hi0, uint32_t lo0, uint32_t c1, uint32_t key,
+                                                  uint32_t &o0, uint32_t &o1)
+{
+    uint32_t c0 = __builtin_amdgcn_bitop3_b32(hi0, key, c1, 0x96);
+    c1 = lo0;
+#pragma unroll
+    for (int r = 1; r < 10; ++r) {
+        const uint64_t prod = (uint64_t)0xD256D193u * (uint64_t)c0;
+        c0 = __builtin_amdgcn_bitop3_b32((uint32_t)(prod >> 32), key + (uint32_t)r * 0x9E3779B9u, c1, 0x96);
+        c1 = (uint32_t)prod;
+    }
+    o0 = c0; o1 = c1;
+}
+
 // 24-bit uniform in [0,1): exactly representable in fp32 and fp64, so the
 // device and the oracle's Philox mode see the same number.
 __device__ __forceinline__ float u24(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }

@@ -36,7 +36,7 @@ struct TraceArgs {
 
 // Launchers (pt_kernels.hip).  All return the hipError_t of the launch.
 hipError_t launch_trace(const TraceArgs &a, const float4 *geom_host, bool reuse_primary,
-                        bool has_specular, bool lds_tiles, hipStream_t s);
+                        bool has_specular, bool lds_tiles, bool steal, hipStream_t s);
 hipError_t launch_primary(const double *prim, int n_obj, int H, int W, double camera_depth,
                           int32_t *idx, double *t, double *normal, hipStream_t s);
 hipError_t launch_rgb8(const float *canvas, uint8_t *rgb, int H, int W, int mode,

@@ -22,6 +22,8 @@
 //   an LDS copy staged once per workgroup.
 #include "pt_internal.hpp"
 
+#include <type_traits>
+
 namespace pt {
 
 // ---------------------------------------------------------------------------
@@ -319,8 +321,209 @@ __global__ __launch_bounds__(NS == -1 ? TILED_BLOCK : TRACE_BLOCK) void trace_ke
     if ((threadIdx.x & 63) == 0 && segs) atomicAdd(a.segments, segs);
 }
 
+// ---------------------------------------------------------------------------
+// trace kernel with wave-level work sharing (the default)
+// ---------------------------------------------------------------------------
+// Phase 1 is trace_kernel's loop unchanged: every lane works through its own
+// pixel's samples in order, no bookkeeping.  It ends, wave-uniformly, the moment
+// the first lane of the wave runs out of samples (or at once if some lanes never
+// had any: primary ray missed or saw a light).  Phase 2 shares what is left:
+// every pixel of the wave gets a counter of samples not yet started (LDS).  A
+// lane whose path ends draws the next sample of the pixel it is working on with
+// one LDS atomic; lanes without a path ballot, pick (wave-uniformly, s_ff1 on the
+// ballot of pixels that still have samples) a pixel to help, draw from ITS
+// counter and load its primary-hit constants from an LDS table.  The wave thus
+// keeps all 64 lanes on live paths until its pool of samples is dry instead of
+// until each lane's own quota is.  Radiance gathered for a foreign pixel goes to
+// a per-pixel LDS accumulator (ds_add_f32) that is added to the canvas at the
+// end.  Philox is keyed by (pixel, global sample, bounce), so WHO traces a
+// sample does not change it; only the fp32 summation order of a pixel's samples
+// can change (PT_FLAG_NO_STEAL keeps the strictly sequential sum).
+template <int NS, bool SPEC>
+__global__ __launch_bounds__(TRACE_BLOCK) void trace_steal_kernel(TraceArgs a, StaticGeom<NS> sg,
+                                                                  const float4 *__restrict__ geom_ro)
+{
+    // geom_ro is the object list again, as a noalias read-only parameter: with LDS
+    // atomics in the loop hipcc otherwise stops proving the list unclobbered and
+    // turns the wave-uniform s_load stream into per-lane vector loads.
+    a.geom = geom_ro;
+    static_assert(NS >= 0, "work sharing is built for the SGPR and scalar-stream object lists");
+    constexpr int BLOCK = TRACE_BLOCK;
+    constexpr int MAT_LDS_STRIDE = 5;
+    __shared__ float4   s_mat[(NS > 0 ? NS : 1) * MAT_LDS_STRIDE];
+    __shared__ uint32_t s_next[BLOCK];          // per pixel: next sample (launch-local index) not started
+    __shared__ float4   s_pix[BLOCK * 3];       // per pixel: P0, d0, colour0, idx0, e0
+    __shared__ float    s_acc[BLOCK * 3];       // per pixel: radiance gathered in phase 2
+    if constexpr (NS > 0) {
+        if ((int)threadIdx.x < min(a.n_obj, NS) * 4)
+            s_mat[(threadIdx.x >> 2) * MAT_LDS_STRIDE + (threadIdx.x & 3)] = a.mat[threadIdx.x];
+    }
+    auto mat = [&](int k, int f) -> float4 {
+        if constexpr (NS > 0) return s_mat[__mul24(k, MAT_LDS_STRIDE) + f];
+        else                  return a.mat[k * 4 + f];
+    };
+
+    const int tid = threadIdx.x;
+    const int wbase = tid & ~63;
+    const int npix = a.height * a.width;
+    const int pixel0 = blockIdx.x * BLOCK;
+    const bool in_canvas = pixel0 + tid < npix;
+    const int pc = in_canvas ? pixel0 + tid : 0;
+    const int pi = pc / a.width, pj = pc - pi * a.width;
+    const uint32_t n = (uint32_t)a.n_samples;
+    const int B = a.max_bounces;
+
+    unsigned long long segs = in_canvas ? 1 : 0;          // the fp64 primary search below
+    f3 acc = mk3(0.f, 0.f, 0.f);
+    if (in_canvas) acc = mk3(a.canvas[3 * (size_t)pc + 0], a.canvas[3 * (size_t)pc + 1], a.canvas[3 * (size_t)pc + 2]);
+
+    // primary segment, once per pixel, fp64 (src/Lib.hs:41-51, :81-98)
+    const PrimaryHit ph = primary_hit_f64(a.prim, a.n_obj, a.height, a.width, a.camera_depth, pi, pj);
+    f3 cd0 = mk3((float)ph.dx, (float)ph.dy, (float)ph.dz);
+    f3 cP0 = mk3((float)(ph.t * ph.dx), (float)(ph.t * ph.dy), (float)(ph.t * ph.dz));
+    f3 ccol = mk3(1.f, 1.f, 1.f);
+    int cidx = ph.idx; float ce = 0.f;
+    bool traced = in_canvas && cidx >= 0 && B >= 2;       // else every sample is black (src/Lib.hs:68,72)
+    __syncthreads();                                       // s_mat is staged
+    if (in_canvas && cidx >= 0) {
+        const float4 m0 = mat(cidx, 0);
+        ce = m0.w; ccol = mk3(m0.x, m0.y, m0.z);
+        if (ce > 0.f) {                                    // the primary ray sees a light (src/Lib.hs:74)
+            for (uint32_t s = 0; s < n; ++s) { acc.x += ce; acc.y += ce; acc.z += ce; }
+            traced = false;
+        }
+    }
+    s_pix[tid * 3 + 0] = make_float4(cP0.x, cP0.y, cP0.z, cd0.x);
+    s_pix[tid * 3 + 1] = make_float4(cd0.y, cd0.z, ccol.x, ccol.y);
+    s_pix[tid * 3 + 2] = make_float4(ccol.z, __int_as_float(cidx), ce, 0.f);
+
+    uint64_t pre = (uint64_t)0xD256D193u * (uint64_t)(uint32_t)pc;
+    f3 o = cP0, d = cd0, thr = ccol;
+    int last = cidx, b = 1;
+    uint32_t sloc = 0;                                     // launch-local index of the sample in flight
+    uint32_t gs = a.sample_begin;
+    bool alive = traced;                                   // has a path in flight
+
+    auto scatter = [&](int idx, float e, f3 din, int bounce) -> f3 {
+        uint32_t r0, r1;
+        philox2x32_10_pre((uint32_t)(pre >> 32), (uint32_t)pre, (gs << 6) | (uint32_t)bounce, a.seed, r0, r1);
+        if constexpr (SPEC) {
+            if (e < 0.f) {                                 // _reflective (src/Lib.hs:110)
+                const float4 m3 = mat(idx, 3);
+                return scatter_specular(din, mk3(m3.y, m3.z, m3.w), u24(r0), u24(r1), NOISE_REV);
+            }
+        }
+        return scatter_diffuse_bits(mat(idx, 1), mat(idx, 2), mat(idx, 3).x, r0, r1);   // src/Lib.hs:111
+    };
+    // One segment: closest-hit search, radiance of a finished path, then `draw`
+    // decides what a finished path does next, then restart or continue.
+    // `all_alive` (compile-time): phase 1 only runs while every lane has a path.
+    auto trip = [&](auto all_alive, auto &&draw) {
+        int k; float t;
+        closest<NS>(a, sg, o, d, last, k, t);
+        const bool live = decltype(all_alive)::value ? true : alive;
+        segs += live ? 1 : 0;
+        const bool hit = k >= 0;
+        const float4 m0 = mat(hit ? k : 0, 0);
+        bool terminal = live && (!hit || (m0.w > 0.f) || (b + 1 >= B));
+        if (terminal && hit && (m0.w > 0.f)) {             // emittance * pixel (src/Lib.hs:74)
+            acc.x = fmaf(m0.w, thr.x, acc.x);
+            acc.y = fmaf(m0.w, thr.y, acc.y);
+            acc.z = fmaf(m0.w, thr.z, acc.z);
+        }
+        draw(terminal);                                    // may clear or set `terminal` (= restart from cP0)
+        int idx = terminal ? cidx : k;
+        if (!decltype(all_alive)::value) idx = max(idx, 0);   // a pathless lane's garbage index stays in range
+        const float e   = terminal ? ce : m0.w;
+        const f3    din = terminal ? cd0 : d;
+        const int   bn  = terminal ? 0 : b;
+        const f3 hp = mk3(terminal ? cP0.x : fmaf(t, d.x, o.x),         // march (src/Object.hs:151-153)
+                          terminal ? cP0.y : fmaf(t, d.y, o.y),
+                          terminal ? cP0.z : fmaf(t, d.z, o.z));
+        thr = mk3(terminal ? ccol.x : thr.x * m0.x,                       // pixel * color (src/Lib.hs:79)
+                  terminal ? ccol.y : thr.y * m0.y,
+                  terminal ? ccol.z : thr.z * m0.z);
+        d = scatter(idx, e, din, bn);
+        o = hp; last = idx; b = bn + 1;
+    };
+
+    if (alive) d = scatter(cidx, ce, cd0, 0);
+
+    // ---- phase 1: every lane on its own pixel --------------------------------
+    const unsigned long long everyone = __ballot(true);
+    // (bottom-tested on purpose: a top-tested form makes hipcc copy ~25 state
+    // registers per trip to keep the pre-trip values alive for the exit path)
+    if (__ballot(alive) == everyone) {
+        do {
+            trip(std::true_type{}, [&](bool &terminal) {
+                if (terminal) { sloc += 1; gs += a.sample_stride; }
+            });
+            alive = sloc < n;
+        } while (__ballot(alive) == everyone);
+    }
+    // A lane that has just left phase 1 restarted a path that does not exist
+    // (sloc == n); it enters phase 2 pathless.
+
+    // ---- phase 2: the wave shares what is left -------------------------------
+    s_next[tid] = alive ? sloc + 1 : n;
+    s_acc[tid * 3 + 0] = 0.f; s_acc[tid * 3 + 1] = 0.f; s_acc[tid * 3 + 2] = 0.f;
+    __syncthreads();
+    int cur = tid;                                         // the pixel (workgroup-relative) this lane works on
+    bool dry = false;                                      // wave-uniform: no pixel has an unstarted sample
+    if (__ballot(alive) != 0ull || !dry) do {
+        trip(std::false_type{}, [&](bool &terminal) {
+            uint32_t sn = 0;
+            if (terminal) sn = atomicAdd(&s_next[cur], 1u);          // next sample of my current pixel
+            const bool want = terminal || !alive;          // lanes that need a (new) path
+            bool needy = want && !(terminal && sn < n);
+            while (!dry && __ballot(needy) != 0ull) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                const bool has = __hip_atomic_load(&s_next[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < n;
+                const unsigned long long avail = __ballot(has);      // pixels of this wave with unstarted samples
+                if (avail == 0ull) { dry = true; break; }
+                const int v = wbase + (__ffsll((long long)avail) - 1);   // wave-uniform choice of pixel to help
+                if (needy) {
+                    sn = atomicAdd(&s_next[v], 1u);
+                    if (sn < n) {
+                        if (v != cur) {                    // hand over what was gathered, adopt pixel v
+                            atomicAdd(&s_acc[cur * 3 + 0], acc.x);
+                            atomicAdd(&s_acc[cur * 3 + 1], acc.y);
+                            atomicAdd(&s_acc[cur * 3 + 2], acc.z);
+                            acc = mk3(0.f, 0.f, 0.f);
+                            cur = v;
+                            const float4 p0 = s_pix[v * 3 + 0], p1 = s_pix[v * 3 + 1], p2 = s_pix[v * 3 + 2];
+                            cP0 = mk3(p0.x, p0.y, p0.z); cd0 = mk3(p0.w, p1.x, p1.y); ccol = mk3(p1.z, p1.w, p2.x);
+                            cidx = __float_as_int(p2.y); ce = p2.z;
+                            pre = (uint64_t)0xD256D193u * (uint64_t)(uint32_t)(pixel0 + v);
+                        }
+                        needy = false;
+                    }
+                }
+            }
+            alive = !want || !needy;                       // path continues, or a sample was drawn
+            terminal = want && !needy;                     // restart from the (current) pixel's primary hit
+            if (terminal) gs = a.sample_begin + sn * a.sample_stride;
+        });
+    } while (__ballot(alive) != 0ull || !dry);
+
+    atomicAdd(&s_acc[cur * 3 + 0], acc.x);
+    atomicAdd(&s_acc[cur * 3 + 1], acc.y);
+    atomicAdd(&s_acc[cur * 3 + 2], acc.z);
+    __syncthreads();
+    if (in_canvas) {
+        a.canvas[3 * (size_t)pc + 0] = s_acc[tid * 3 + 0];
+        a.canvas[3 * (size_t)pc + 1] = s_acc[tid * 3 + 1];
+        a.canvas[3 * (size_t)pc + 2] = s_acc[tid * 3 + 2];
+    }
+
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) segs += __shfl_down(segs, off, 64);
+    if ((tid & 63) == 0 && segs) atomicAdd(a.segments, segs);
+}
+
 template <int NS>
-static hipError_t launch_trace_ns(TraceArgs a, const float4 *geom_host, bool reuse, bool spec, hipStream_t s)
+static hipError_t launch_trace_ns(TraceArgs a, const float4 *geom_host, bool reuse, bool spec, bool steal,
+                                  hipStream_t s)
 {
     // pad the by-value object list to NS with records that never pass the
     // 0 < t < Inf guard (n = 0 gives t = NaN)
@@ -339,6 +542,13 @@ static hipError_t launch_trace_ns(TraceArgs a, const float4 *geom_host, bool reu
     }
     const int npix = a.height * a.width;
     const dim3 grid((npix + BLOCK - 1) / BLOCK), block(BLOCK);
+    if constexpr (NS >= 0) {
+        if (steal && reuse) {
+            if (spec) hipLaunchKernelGGL((trace_steal_kernel<NS, true>), grid, block, 0, s, a, sg, a.geom);
+            else      hipLaunchKernelGGL((trace_steal_kernel<NS, false>), grid, block, 0, s, a, sg, a.geom);
+            return hipGetLastError();
+        }
+    }
     if (reuse) {
         if (spec) hipLaunchKernelGGL((trace_kernel<NS, true, true>), grid, block, smem, s, a, sg);
         else      hipLaunchKernelGGL((trace_kernel<NS, true, false>), grid, block, smem, s, a, sg);
@@ -350,12 +560,12 @@ static hipError_t launch_trace_ns(TraceArgs a, const float4 *geom_host, bool reu
 }
 
 hipError_t launch_trace(const TraceArgs &a, const float4 *geom_host, bool reuse, bool spec, bool lds_tiles,
-                        hipStream_t s)
+                        bool steal, hipStream_t s)
 {
-    if (a.n_obj <= 4) return launch_trace_ns<4>(a, geom_host, reuse, spec, s);
-    if (a.n_obj <= MAX_STATIC_OBJECTS) return launch_trace_ns<MAX_STATIC_OBJECTS>(a, geom_host, reuse, spec, s);
-    if (lds_tiles) return launch_trace_ns<-1>(a, geom_host, reuse, spec, s);
-    return launch_trace_ns<0>(a, geom_host, reuse, spec, s);
+    if (a.n_obj <= 4) return launch_trace_ns<4>(a, geom_host, reuse, spec, steal, s);
+    if (a.n_obj <= MAX_STATIC_OBJECTS) return launch_trace_ns<MAX_STATIC_OBJECTS>(a, geom_host, reuse, spec, steal, s);
+    if (lds_tiles) return launch_trace_ns<-1>(a, geom_host, reuse, spec, false, s);
+    return launch_trace_ns<0>(a, geom_host, reuse, spec, steal, s);
 }
 
 // ---------------------------------------------------------------------------

@@ -269,10 +269,10 @@ def test_primary_light_scene(pa):
 
 
 def test_chunking_is_bit_exact(pa):
-    """k calls of pt_trace(1) == one call of pt_trace(k), bit for bit, and the
-    canvas is the running SUM (traces !! k), element 0 black."""
+    """Under PT_FLAG_NO_STEAL k calls of pt_trace(1) == one call of pt_trace(k), bit
+    for bit, and the canvas is the running SUM (traces !! k), element 0 black."""
     P = pa.Params(50, 70, 500.0, 6, 5)
-    with pa.Renderer(P, seed=2) as a, pa.Renderer(P, seed=2) as b:
+    with pa.Renderer(P, seed=2, flags=pa.PT_FLAG_NO_STEAL) as a, pa.Renderer(P, seed=2, flags=pa.PT_FLAG_NO_STEAL) as b:
         assert not a.read_sum_f32().any()
         a.trace(6)
         for _ in range(6):
@@ -282,6 +282,26 @@ def test_chunking_is_bit_exact(pa):
         assert a.segments == b.segments - 5 * 50 * 70      # b recomputed the primary hit per launch
         a.reset()
         assert not a.read_sum_f32().any() and a.samples_done == 0 and a.segments == 0
+
+
+@pytest.mark.parametrize("H,W,spp,bounces", [(50, 70, 6, 5), (64, 64, 40, 8), (33, 31, 17, 30)])
+def test_work_sharing_renders_the_same_paths(pa, H, W, spp, bounces):
+    """Default mode (idle lanes help other pixels of their wave) against the strict
+    per-lane mode: same Philox-keyed paths, so the same number of closest-hit
+    searches and the same sums up to fp32 summation order; chunked calls likewise."""
+    P = pa.Params(H, W, 500.0, spp, bounces)
+    with pa.Renderer(P, seed=6) as steal, pa.Renderer(P, seed=6, flags=pa.PT_FLAG_NO_STEAL) as strict, \
+            pa.Renderer(P, seed=6) as chunked:
+        steal.trace(spp)
+        strict.trace(spp)
+        for n in (1, 2, spp - 3):
+            chunked.trace(n)
+        a, b, c = steal.read_sum_f32(), strict.read_sum_f32(), chunked.read_sum_f32()
+        assert steal.segments == strict.segments
+        assert chunked.segments == strict.segments + 2 * H * W
+    assert np.allclose(a, b, rtol=2e-6, atol=1e-6)
+    assert np.allclose(c, b, rtol=2e-6, atol=1e-6)
+    assert b.sum() > 0
 
 
 def test_traces_generator(pa):
