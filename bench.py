@@ -110,7 +110,6 @@ def main():
                     flags=flags)
     stream = torch.cuda.current_stream()
     r.set_stream(stream.cuda_stream)          # kernels, all-reduce and events share torch's stream
-    r.set_timing(True)
 
     # the context's canvas as a torch tensor (no copy), for the all-reduce
     canvas = canvas_tensor(r, local_rank)
@@ -142,14 +141,14 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
 
-    # kernel duration of the last timed step's trace launch(es), HIP events on the launch stream
-    ms_last, launches = r.last_trace_ms()
-    # a separate, individually event-timed pass for the roofline average
+    # a separate, individually event-timed pass for the roofline average (HIP events on the launch stream)
+    r.set_timing(True)
     ev = []
     for _ in range(min(args.steps, 5)):
         r.reset()
         r.trace(my_spp)
-        ev.append(r.last_trace_ms()[0])
+        ms_one, launches = r.last_trace_ms()
+        ev.append(ms_one)
     fence()
     kern_ms = sum(ev) / len(ev) / max(launches, 1)
 

@@ -114,7 +114,11 @@ int pt_scene_upload(pt_ctx *ctx, const pt_object *objs, int32_t n);
  * after the work is queued on the context's stream. */
 int pt_trace(pt_ctx *ctx, int32_t iters);
 
-/* Zero the canvas and the sample/segment counters (back to `traces !! 0`). */
+/* Zero the canvas and the sample/segment counters (back to `traces !! 0`).
+ * The device buffer is zeroed lazily (by the next pt_trace, which then starts
+ * from zero without reading it, or by the next read): a host holding the raw
+ * pointer of pt_canvas_device_ptr must not read it between pt_reset and the
+ * next pt_trace. */
 int pt_reset(pt_ctx *ctx);
 
 /* Element `samples_done` of Lib.traces (src/Lib.hs:53-56): the SUM (not mean)

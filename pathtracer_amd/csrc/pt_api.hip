@@ -20,7 +20,9 @@ struct pt_ctx {
     pt_params p{};
     hipStream_t own_stream = nullptr, stream = nullptr;
     float *d_canvas = nullptr;
-    unsigned long long *d_segments = nullptr;
+    unsigned long long *d_segments = nullptr;   // ring of SEG_SLOTS counters, one per pt_reset epoch
+    int seg_slot = 0;
+    bool canvas_stale = false;                   // pt_reset defers the zeroing to the next pt_trace / read
     float4 *d_geom = nullptr, *d_mat = nullptr;
     double *d_prim = nullptr;
     uint8_t *d_rgb = nullptr;
@@ -43,6 +45,7 @@ constexpr int64_t MAX_GLOBAL_SAMPLES = (int64_t)1 << 26;   // sample index share
 constexpr int     MAX_BOUNCES = 64;
 constexpr int     MAX_OBJECTS = 65536;
 constexpr int     MAX_SAMPLES_PER_LAUNCH = 4096;
+constexpr int     SEG_SLOTS = 1024;
 
 int fail(pt_ctx *c, int status, const std::string &msg)
 {
@@ -202,10 +205,10 @@ int pt_create(pt_ctx **out, const pt_params *params)
     c->stream = c->own_stream;
     const size_t cbytes = npix(c) * 3 * sizeof(float);
     if ((e = hipMalloc((void **)&c->d_canvas, cbytes)) != hipSuccess) return bail("hipMalloc(canvas)", e);
-    if ((e = hipMalloc((void **)&c->d_segments, sizeof(unsigned long long))) != hipSuccess)
+    if ((e = hipMalloc((void **)&c->d_segments, SEG_SLOTS * sizeof(unsigned long long))) != hipSuccess)
         return bail("hipMalloc(segments)", e);
     if ((e = hipMemsetAsync(c->d_canvas, 0, cbytes, c->stream)) != hipSuccess) return bail("hipMemset", e);
-    if ((e = hipMemsetAsync(c->d_segments, 0, sizeof(unsigned long long), c->stream)) != hipSuccess)
+    if ((e = hipMemsetAsync(c->d_segments, 0, SEG_SLOTS * sizeof(unsigned long long), c->stream)) != hipSuccess)
         return bail("hipMemset", e);
     if ((e = hipEventCreate(&c->ev0)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipEventCreate(&c->ev1)) != hipSuccess) return bail("hipEventCreate", e);
@@ -290,7 +293,8 @@ int pt_trace(pt_ctx *c, int32_t iters)
     while (left > 0) {
         const int32_t n = left < MAX_SAMPLES_PER_LAUNCH ? left : MAX_SAMPLES_PER_LAUNCH;
         TraceArgs a{};
-        a.canvas = c->d_canvas; a.segments = c->d_segments;
+        a.canvas = c->d_canvas; a.segments = c->d_segments + c->seg_slot;
+        a.fresh = c->canvas_stale ? 1 : 0;           // the canvas is logically zero: do not read it
         a.geom = c->d_geom; a.mat = c->d_mat; a.prim = c->d_prim;
         a.camera_depth = c->p.camera_depth;
         a.n_obj = c->n_obj; a.height = c->p.height; a.width = c->p.width;
@@ -301,6 +305,7 @@ int pt_trace(pt_ctx *c, int32_t iters)
         PT_HIP(c, launch_trace(a, c->h_geom.data(), reuse, c->has_specular,
                                (c->p.flags & PT_FLAG_LDS_TILES) != 0,
                                (c->p.flags & PT_FLAG_NO_STEAL) == 0, c->stream));
+        c->canvas_stale = false;
         c->samples_done += n;
         left -= n;
         ++launches;
@@ -313,11 +318,27 @@ int pt_trace(pt_ctx *c, int32_t iters)
     return PT_OK;
 }
 
+// The canvas is zeroed lazily: the next pt_trace starts its sums from zero
+// without reading the buffer (saving a 25-MB fill and a 25-MB read per frame at
+// 1080p), and any read before that zeroes it first.  The segment counter moves
+// to the next slot of a pre-zeroed ring instead of being cleared.
+static int materialise_canvas(pt_ctx *c)
+{
+    if (c->canvas_stale) {
+        PT_HIP(c, hipMemsetAsync(c->d_canvas, 0, npix(c) * 3 * sizeof(float), c->stream));
+        c->canvas_stale = false;
+    }
+    return PT_OK;
+}
+
 int pt_reset(pt_ctx *c)
 {
     if (int s = check_ctx(c)) return s;
-    PT_HIP(c, hipMemsetAsync(c->d_canvas, 0, npix(c) * 3 * sizeof(float), c->stream));
-    PT_HIP(c, hipMemsetAsync(c->d_segments, 0, sizeof(unsigned long long), c->stream));
+    c->canvas_stale = true;
+    if (++c->seg_slot == SEG_SLOTS) {
+        PT_HIP(c, hipMemsetAsync(c->d_segments, 0, SEG_SLOTS * sizeof(unsigned long long), c->stream));
+        c->seg_slot = 0;
+    }
     c->samples_done = 0;
     return PT_OK;
 }
@@ -326,6 +347,7 @@ int pt_read_sum_f32(pt_ctx *c, float *out)
 {
     if (int s = check_ctx(c)) return s;
     if (!out) return fail(c, PT_ERR_INVALID, "pt_read_sum_f32: null output");
+    if (int s = materialise_canvas(c)) return s;
     PT_HIP(c, hipMemcpyAsync(out, c->d_canvas, npix(c) * 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     PT_HIP(c, hipStreamSynchronize(c->stream));
     return PT_OK;
@@ -347,6 +369,7 @@ int pt_rgb8_device(pt_ctx *c, void *d_out, int32_t mode, int64_t samples_overrid
     if (!d_out) return fail(c, PT_ERR_INVALID, "pt_rgb8_device: null output");
     if (mode < PT_RGB8_REFERENCE || mode > PT_RGB8_MEAN_GAMMA)
         return fail(c, PT_ERR_INVALID, "pt_rgb8_device: unknown mode");
+    if (int s = materialise_canvas(c)) return s;
     const int64_t ns = samples_override > 0 ? samples_override : c->samples_done;
     const double inv = ns > 0 ? 1.0 / (double)ns : 0.0;
     PT_HIP(c, launch_rgb8(c->d_canvas, (uint8_t *)d_out, c->p.height, c->p.width, mode, inv, c->stream));
@@ -396,7 +419,7 @@ int pt_segments(pt_ctx *c, uint64_t *out)
     if (int s = check_ctx(c)) return s;
     if (!out) return fail(c, PT_ERR_INVALID, "pt_segments: null output");
     unsigned long long v = 0;
-    PT_HIP(c, hipMemcpyAsync(&v, c->d_segments, sizeof v, hipMemcpyDeviceToHost, c->stream));
+    PT_HIP(c, hipMemcpyAsync(&v, c->d_segments + c->seg_slot, sizeof v, hipMemcpyDeviceToHost, c->stream));
     PT_HIP(c, hipStreamSynchronize(c->stream));
     *out = (uint64_t)v;
     return PT_OK;
@@ -412,6 +435,8 @@ int pt_samples_done(pt_ctx *c, int64_t *out)
 int pt_canvas_device_ptr(pt_ctx *c, void **dptr, size_t *bytes)
 {
     if (!c || !dptr) return fail(c, PT_ERR_INVALID, "pt_canvas_device_ptr: null argument");
+    if (int s = check_ctx(c)) return s;
+    if (int s = materialise_canvas(c)) return s;
     *dptr = c->d_canvas;
     if (bytes) *bytes = npix(c) * 3 * sizeof(float);
     return PT_OK;
@@ -438,6 +463,7 @@ int pt_write_sum_f32(pt_ctx *c, const float *in, int64_t samples_done)
     if (!in || samples_done < 0) return fail(c, PT_ERR_INVALID, "pt_write_sum_f32: bad argument");
     PT_HIP(c, hipMemcpyAsync(c->d_canvas, in, npix(c) * 3 * sizeof(float), hipMemcpyHostToDevice, c->stream));
     PT_HIP(c, hipStreamSynchronize(c->stream));
+    c->canvas_stale = false;
     c->samples_done = samples_done;
     return PT_OK;
 }

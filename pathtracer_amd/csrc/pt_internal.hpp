@@ -31,6 +31,7 @@ struct TraceArgs {
     uint32_t sample_begin;             // global index of this launch's first sample
     uint32_t sample_stride;
     int      n_samples;                // samples per pixel in this launch
+    int      fresh;                    // 1: the canvas is logically zero, start the sums at 0 without reading it
     int      tile_objs;                // objects per LDS tile (tiled kernel; set by the launcher)
 };
 

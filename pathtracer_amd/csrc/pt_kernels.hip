@@ -208,7 +208,7 @@ __global__ __launch_bounds__(NS == -1 ? TILED_BLOCK : TRACE_BLOCK) void trace_ke
     // traceCanvas adds onto the running sum (src/Lib.hs:65); continuing the
     // fp32 sum sample by sample makes k launches of 1 equal 1 launch of k.
     f3 acc = mk3(0.f, 0.f, 0.f);
-    if (in_canvas) acc = mk3(a.canvas[3 * (size_t)pc + 0], a.canvas[3 * (size_t)pc + 1], a.canvas[3 * (size_t)pc + 2]);
+    if (in_canvas && !a.fresh) acc = mk3(a.canvas[3 * (size_t)pc + 0], a.canvas[3 * (size_t)pc + 1], a.canvas[3 * (size_t)pc + 2]);
 
     // Primary segment: no jitter, no randomness (src/Lib.hs:41-51), so it is
     // computed once per pixel, in fp64, reference operation order.
@@ -375,7 +375,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_steal_kernel(TraceArgs a, S
 
     unsigned long long segs = in_canvas ? 1 : 0;          // the fp64 primary search below
     f3 acc = mk3(0.f, 0.f, 0.f);
-    if (in_canvas) acc = mk3(a.canvas[3 * (size_t)pc + 0], a.canvas[3 * (size_t)pc + 1], a.canvas[3 * (size_t)pc + 2]);
+    if (in_canvas && !a.fresh) acc = mk3(a.canvas[3 * (size_t)pc + 0], a.canvas[3 * (size_t)pc + 1], a.canvas[3 * (size_t)pc + 2]);
 
     // primary segment, once per pixel, fp64 (src/Lib.hs:41-51, :81-98)
     const PrimaryHit ph = primary_hit_f64(a.prim, a.n_obj, a.height, a.width, a.camera_depth, pi, pj);

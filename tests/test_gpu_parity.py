@@ -418,3 +418,23 @@ def test_against_committed_golden_fixtures(pa):
         dev = r.read_sum()
     for k in range(3):
         assert abs(dev[..., k].mean() - f["sum"][..., k].mean()) <= 0.01 * f["sum"][..., k].mean()
+
+
+def test_reset_is_lazy_but_exact(pa):
+    """pt_reset defers the zeroing of the canvas to the next pt_trace (which starts
+    from zero without reading it) or the next read: results must equal a fresh
+    context's, segment counts restart, and the raw device pointer reads zero after
+    a reset + read."""
+    P = pa.Params(40, 52, 500.0, 5, 6)
+    with pa.Renderer(P, seed=8) as a, pa.Renderer(P, seed=8) as fresh:
+        a.trace(7)
+        a.reset()
+        a.trace(5)
+        fresh.trace(5)
+        assert np.array_equal(a.read_sum_f32(), fresh.read_sum_f32())
+        assert a.segments == fresh.segments and a.samples_done == 5
+        for _ in range(3):                                 # repeated resets, nothing in between
+            a.reset()
+        assert not a.read_sum_f32().any() and a.segments == 0
+        a.reset()
+        assert a.read_rgb8().max() == 0
