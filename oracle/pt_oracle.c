@@ -473,6 +473,40 @@ void o_trace(const o_params *p, const o_object *objs, int n,
     (void)threads;
 }
 
+void o_trace_pixels(const o_params *p, const o_object *objs, int n, const int32_t *pixels, int64_t count,
+                    o_stdgen *gens, int64_t s_begin, int64_t iters, int64_t stride,
+                    double *sum, double *sumsq, uint64_t *segments, int threads)
+{
+    uint64_t total = 0;
+    const int W = p->width;
+    if (stride < 1) stride = 1;
+#ifdef _OPENMP
+    if (threads < 1) threads = 1;
+#pragma omp parallel for schedule(dynamic, 16) num_threads(threads) reduction(+:total)
+#endif
+    for (int64_t q = 0; q < count; ++q) {
+        const size_t px = (size_t)pixels[q];
+        const int i = (int)(px / W), j = (int)(px % W);
+        o_vec3 zero = { 0, 0, 0 };
+        o_vec3 dir = o_primary_direction(p, i, j);
+        for (int64_t it = 0; it < iters; ++it) {
+            draw_state d;
+            d.mode = p->rng; d.gen = gens ? &gens[q] : 0;     /* gens: one per LISTED pixel */
+            d.pixel = (uint32_t)px; d.seed = p->seed;
+            d.sample = (uint64_t)(s_begin + it * stride); d.bounce = 0;
+            uint64_t segs = 0;
+            o_vec3 c = terminal_color(p, objs, n, zero, dir, &d, &segs);
+            total += segs;
+            sum[q * 3 + 0] += c.x; sum[q * 3 + 1] += c.y; sum[q * 3 + 2] += c.z;
+            if (sumsq) {
+                sumsq[q * 3 + 0] += c.x * c.x; sumsq[q * 3 + 1] += c.y * c.y; sumsq[q * 3 + 2] += c.z * c.z;
+            }
+        }
+    }
+    if (segments) *segments += total;
+    (void)threads;
+}
+
 /* ------------------------------------------------------------------------ */
 /* Conversion.hs                                                             */
 /* ------------------------------------------------------------------------ */

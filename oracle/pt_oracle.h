@@ -130,6 +130,12 @@ void o_trace(const o_params *p, const o_object *objs, int n,
              o_stdgen *gens, int64_t s_begin, int64_t iters, int64_t sample_stride,
              double *sum, double *sumsq, uint64_t *segments, int threads);
 
+/* Same as o_trace for a chosen subset of pixels (spot checks at full canvas
+ * sizes): pixels[k] = i*W + j; sum/sumsq hold 3 values per listed pixel. */
+void o_trace_pixels(const o_params *p, const o_object *objs, int n, const int32_t *pixels, int64_t count,
+                    o_stdgen *gens, int64_t s_begin, int64_t iters, int64_t sample_stride,
+                    double *sum, double *sumsq, uint64_t *segments, int threads);
+
 /* ---- Conversion.hs ------------------------------------------------------ */
 /* listToPixelRGB8 (src/Conversion.hs:17-20): round-half-even of 255*x, then
  * Int -> Word8 wrap. */

@@ -61,6 +61,9 @@ def _load():
         "o_starting_gens": (None, [C.POINTER(OParams), C.c_void_p]),
         "o_trace": (None, [C.POINTER(OParams), C.POINTER(OObject), C.c_int, C.c_void_p, C.c_int64, C.c_int64,
                            C.c_int64, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.c_int]),
+        "o_trace_pixels": (None, [C.POINTER(OParams), C.POINTER(OObject), C.c_int, C.c_void_p, C.c_int64, C.c_void_p,
+                                  C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64),
+                                  C.c_int]),
         "o_to_word8": (C.c_uint8, [d]),
         "o_repa3_to_image": (None, [C.POINTER(OParams), C.c_void_p, C.c_void_p]),
     }
@@ -126,6 +129,17 @@ class Tracer:
                   self.sumsq.ctypes.data, C.byref(self.segments), self.threads)
         self.done += iters
         return self.sum
+
+
+def trace_pixels(p, objs, pixels, iters, s_begin=0, stride=1, threads=8):
+    """Philox-stream sums of the listed pixels (i*W + j) only: (len(pixels), 3)."""
+    assert p.rng == PHILOX
+    pixels = np.ascontiguousarray(pixels, np.int32)
+    out = np.zeros((len(pixels), 3), np.float64)
+    segs = C.c_uint64(0)
+    L.o_trace_pixels(C.byref(p), objs, len(objs), pixels.ctypes.data, len(pixels), None, s_begin, iters, stride,
+                     out.ctypes.data, None, C.byref(segs), threads)
+    return out, segs.value
 
 
 def repa3_to_image(p, canvas):
