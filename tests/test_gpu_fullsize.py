@@ -63,16 +63,23 @@ def test_spot_check_pixels_at_bench_size(pa, spp, flags):
         dev = r.read_sum().reshape(-1, 3)[px]
         segs = r.segments
     ora, _ = O.trace_pixels(O.params(H, W, DEPTH, BOUNCES, O.PHILOX, 0), O.default_scene(), px, spp)
-    # same draws on both sides: a pixel differs only where fp32/fp64 rounding flipped a hit
-    # on one of its spp paths; per path that is rare, per pixel it scales with spp
+    # Same draws on both sides: a pixel differs only where fp32/fp64 rounding flips a hit.
+    # Measured on MI355X: every one of the ~1,500 ordinary pixels agrees to <= 4e-4 absolute
+    # at 1024 spp.  The exception is the analytic TIE LINES: there the primary
+    # hit point lies on two planes at once, so whether a bounce ray "sees" the second plane
+    # is decided by the last bit of the hit point -- in the reference's fp64 as much as in
+    # fp32.  Their primary hits are bit-exact (test above); their sums are only sanity-bounded.
+    ii, jj = px // W, px % W
+    tie = (jj == W // 2 - 100) | (ii == H // 2 - 100)
+    assert 20 <= tie.sum() <= 80
     rel = np.abs(dev - ora) / np.maximum(np.abs(ora), 1e-9)
-    close = (rel <= 2e-4).all(axis=1)
-    assert close.mean() >= (0.90 if spp >= 1024 else 0.97), close.mean()
-    # and no pixel is off by more than a handful of paths' worth of radiance
-    # (one flipped path changes the sum by at most emittance * 1 = 2 per channel)
-    assert np.max(np.abs(dev - ora)) <= 16.0
+    close = (rel[~tie] <= 2e-4).all(axis=1)
+    assert close.mean() >= 0.995, close.mean()
+    # one flipped path moves a sum by at most emittance * 1 = 2 per channel
+    assert np.max(np.abs(dev[~tie] - ora[~tie])) <= 8.0
+    assert np.all(np.isfinite(dev)) and dev.min() >= 0.0 and dev.max() <= 2.0 * spp
     # means over the spot set agree far below the Monte-Carlo noise
-    assert np.all(np.abs(dev.mean(0) - ora.mean(0)) <= 2e-3 * ora.mean(0))
+    assert np.all(np.abs(dev[~tie].mean(0) - ora[~tie].mean(0)) <= 1e-4 * ora[~tie].mean(0))
     # executed searches: bounded by paths * depth, above paths * 1
     assert H * W * spp <= segs <= H * W * spp * BOUNCES
 
