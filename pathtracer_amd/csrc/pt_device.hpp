@@ -71,6 +71,39 @@ __device__ __forceinline__ void philox2x32_10(uint32_t c0, uint32_t c1, uint32_t
 // The same generator with the first round's product M * c0 supplied by the
 // caller: the trace kernel's c0 is the pixel index, constant for as long as a
 // lane works on one pixel, so that multiply leaves the per-segment loop.
+// Round keys and multiplier held in VGPRs (wave-uniform values in vector
+// registers): a VALU instruction that reads an SGPR can issue only once per
+// 4 cycles on gfx950 against 2 for an all-VGPR one (tools/ubench_issue.hip), and
+// the trace loop already spends that budget on the object list.
+struct PhiloxRegs { uint32_t k[10]; uint32_t m; };
+__device__ __forceinline__ uint32_t to_vgpr(uint32_t x)
+{
+    uint32_t v;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "s"(x));
+    return v;
+}
+__device__ __forceinline__ PhiloxRegs philox_regs(uint32_t key)
+{
+    PhiloxRegs p;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) p.k[r] = to_vgpr(key + (uint32_t)r * 0x9E3779B9u);
+    p.m = to_vgpr(0xD256D193u);
+    return p;
+}
+__device__ __forceinline__ void philox2x32_10_pre_v(uint32_t hi0, uint32_t lo0, uint32_t c1, const PhiloxRegs &p,
+                                                    uint32_t &o0, uint32_t &o1)
+{
+    uint32_t c0 = __builtin_amdgcn_bitop3_b32(hi0, p.k[0], c1, 0x96);
+    c1 = lo0;
+#pragma unroll
+    for (int r = 1; r < 10; ++r) {
+        const uint64_t prod = (uint64_t)p.m * (uint64_t)c0;
+        c0 = __builtin_amdgcn_bitop3_b32((uint32_t)(prod >> 32), p.k[r], c1, 0x96);
+        c1 = (uint32_t)prod;
+    }
+    o0 = c0; o1 = c1;
+}
+
 __device__ __forceinline__ void philox2x32_10_pre(uint32_t hi0, uint32_t lo0, uint32_t c1, uint32_t key,
                                                   uint32_t &o0, uint32_t &o1)
 {

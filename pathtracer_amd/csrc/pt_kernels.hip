@@ -22,6 +22,10 @@
 //   an LDS copy staged once per workgroup.
 #include "pt_internal.hpp"
 
+#ifndef PT_EXP
+#define PT_EXP 0
+#endif
+
 #include <type_traits>
 
 namespace pt {
@@ -348,6 +352,24 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_steal_kernel(TraceArgs a, S
     // turns the wave-uniform s_load stream into per-lane vector loads.
     a.geom = geom_ro;
     static_assert(NS >= 0, "work sharing is built for the SGPR and scalar-stream object lists");
+    if constexpr (NS > 0) {
+        auto fv = [](float &x) { x = __uint_as_float(to_vgpr(__float_as_uint(x))); };
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+#if PT_EXP & 8
+            fv(sg.g[k][2].x); fv(sg.g[k][2].y); fv(sg.g[k][2].z);                     // disk centre
+#endif
+#if PT_EXP & 16
+            fv(sg.g[k][0].x); fv(sg.g[k][0].y); fv(sg.g[k][0].z); fv(sg.g[k][0].w);   // n_raw, A
+#endif
+#if PT_EXP & 32
+            fv(sg.g[k][1].x); fv(sg.g[k][1].y); fv(sg.g[k][1].z);                     // n_hat
+#endif
+#if PT_EXP & 64
+            fv(sg.g[k][0].w);                                                         // A only
+#endif
+        }
+    }
     constexpr int BLOCK = TRACE_BLOCK;
     constexpr int MAT_LDS_STRIDE = 5;
     __shared__ float4   s_mat[(NS > 0 ? NS : 1) * MAT_LDS_STRIDE];
@@ -404,9 +426,16 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_steal_kernel(TraceArgs a, S
     uint32_t gs = a.sample_begin;
     bool alive = traced;                                   // has a path in flight
 
+#if PT_EXP & 1
+    const PhiloxRegs pregs = philox_regs(a.seed);
+#endif
     auto scatter = [&](int idx, float e, f3 din, int bounce) -> f3 {
         uint32_t r0, r1;
+#if PT_EXP & 1
+        philox2x32_10_pre_v((uint32_t)(pre >> 32), (uint32_t)pre, (gs << 6) | (uint32_t)bounce, pregs, r0, r1);
+#else
         philox2x32_10_pre((uint32_t)(pre >> 32), (uint32_t)pre, (gs << 6) | (uint32_t)bounce, a.seed, r0, r1);
+#endif
         if constexpr (SPEC) {
             if (e < 0.f) {                                 // _reflective (src/Lib.hs:110)
                 const float4 m3 = mat(idx, 3);
@@ -422,15 +451,28 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_steal_kernel(TraceArgs a, S
         int k; float t;
         closest<NS>(a, sg, o, d, last, k, t);
         const bool live = decltype(all_alive)::value ? true : alive;
+#if PT_EXP & 4
+        if (!decltype(all_alive)::value) segs += live ? 1 : 0;      // phase 1 counts its trips wave-uniformly
+#else
         segs += live ? 1 : 0;
+#endif
         const bool hit = k >= 0;
         const float4 m0 = mat(hit ? k : 0, 0);
         bool terminal = live && (!hit || (m0.w > 0.f) || (b + 1 >= B));
+#if PT_EXP & 2
+        {                                                  // emittance * pixel (src/Lib.hs:74)
+            const float E = (live && hit) ? fmaxf(m0.w, 0.f) : 0.f;   // e <= 0: not a light
+            acc.x = fmaf(E, thr.x, acc.x);
+            acc.y = fmaf(E, thr.y, acc.y);
+            acc.z = fmaf(E, thr.z, acc.z);
+        }
+#else
         if (terminal && hit && (m0.w > 0.f)) {             // emittance * pixel (src/Lib.hs:74)
             acc.x = fmaf(m0.w, thr.x, acc.x);
             acc.y = fmaf(m0.w, thr.y, acc.y);
             acc.z = fmaf(m0.w, thr.z, acc.z);
         }
+#endif
         draw(terminal);                                    // may clear or set `terminal` (= restart from cP0)
         int idx = terminal ? cidx : k;
         if (!decltype(all_alive)::value) idx = max(idx, 0);   // a pathless lane's garbage index stays in range
@@ -454,12 +496,17 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_steal_kernel(TraceArgs a, S
     // (bottom-tested on purpose: a top-tested form makes hipcc copy ~25 state
     // registers per trip to keep the pre-trip values alive for the exit path)
     if (__ballot(alive) == everyone) {
+        uint32_t trips = 0;                                // wave-uniform (SALU)
         do {
             trip(std::true_type{}, [&](bool &terminal) {
                 if (terminal) { sloc += 1; gs += a.sample_stride; }
             });
             alive = sloc < n;
+            trips += 1;
         } while (__ballot(alive) == everyone);
+#if PT_EXP & 4
+        segs += trips;
+#endif
     }
     // A lane that has just left phase 1 restarted a path that does not exist
     // (sloc == n); it enters phase 2 pathless.
@@ -521,6 +568,243 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_steal_kernel(TraceArgs a, S
     if ((tid & 63) == 0 && segs) atomicAdd(a.segments, segs);
 }
 
+// ---------------------------------------------------------------------------
+// trace kernel for small scenes (object list in the kernel arguments), the
+// default for <= 8 objects.  Same two phases and the same work sharing as
+// trace_steal_kernel; what differs is the instruction diet, shaped by the issue
+// rules measured with tools/ubench_issue.hip on gfx950:
+//   * a VALU instruction with an SGPR operand issues once per 4 cycles, an
+//     all-VGPR add/mul/fma/logic op once per 2, and compares, selects, min/max,
+//     converts, integer multiplies and three-operand integer ops once per 4 on a
+//     port of their own; the three limits overlap, so the loop is laid out to
+//     load them evenly: n_hat stays in SGPRs (den = v.n_hat), n_raw and A move to
+//     VGPRs, and the Philox round keys and multiplier are VGPRs too;
+//   * object identity is carried as the byte offset 16*(k+1) of the object's
+//     material record (0 = the "miss" record), so the closest-hit search selects
+//     LDS addresses directly from inline constants: no index arithmetic;
+//   * the material tag m0.w orders the cases (light e > 0, miss 0, diffuse -1,
+//     reflective -2): "path ends here" is one compare and the emitted radiance
+//     max(e, 0) one integer max, with no select on hit/miss;
+//   * sample index and bounce live in one counter (gs << 6 | bounce) that is
+//     also the Philox counter word and the loop's exit test.
+// ---------------------------------------------------------------------------
+template <int NS>
+__device__ __forceinline__ void closest_static(const StaticGeom<NS> &sg, f3 o, f3 v, int lastp, int &bestp,
+                                               float &best_t)
+{
+    // keys as in test_object_key: bits(t) - 1, valid iff below KEY_LIMIT, strict '<' keeps the earlier object
+    uint32_t best_key = KEY_LIMIT;
+    bestp = 0;
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+        const float4 g0 = sg.g[k][0], g1 = sg.g[k][1], g2 = sg.g[k][2];
+        const float on  = fmaf(o.z, g0.z, fmaf(o.y, g0.y, o.x * g0.x));
+        const float den = fmaf(v.z, g1.z, fmaf(v.y, g1.y, v.x * g1.x));
+        const float t = (g0.w - on) * __builtin_amdgcn_rcpf(den);
+        const uint32_t key = __float_as_uint(t) - 1u;
+        bool ok = (key < best_key) & (16 * (k + 1) != lastp);     // 0 < t < best, not _lastStruck (src/Lib.hs:86-90)
+        if (g1.w != __builtin_inff()) {                            // wave-uniform: Disk (src/Object.hs:165-171)
+            const float dx = fmaf(t, v.x, o.x) - g2.x;
+            const float dy = fmaf(t, v.y, o.y) - g2.y;
+            const float dz = fmaf(t, v.z, o.z) - g2.z;
+            ok = ok & (fmaf(dz, dz, fmaf(dy, dy, dx * dx)) < g1.w);
+        }
+        bestp = ok ? 16 * (k + 1) : bestp;
+        best_key = ok ? key : best_key;
+    }
+    best_t = __uint_as_float(best_key + 1u);
+}
+
+template <int NS, bool SPEC>
+__global__ __launch_bounds__(TRACE_BLOCK) void trace_static_kernel(TraceArgs a, StaticGeom<NS> sg)
+{
+    static_assert(NS > 0, "object list by value");
+    constexpr int BLOCK = TRACE_BLOCK;
+    constexpr int R = NS + 1;                       // material records per field: miss + NS objects
+    __shared__ float4   s_mat[4 * R];               // field f of object k at [f*R + k + 1]; [f*R] = miss
+    __shared__ uint32_t s_next[BLOCK];              // per pixel: next global sample index not started
+    __shared__ float4   s_pix[BLOCK * 3];           // per pixel: P0, d0, colour0, idx0, e0
+    __shared__ float    s_acc[BLOCK * 3];           // per pixel: radiance gathered in phase 2
+    const int tid = threadIdx.x;
+    if (tid < 4 * R) {
+        const int f = tid / R, r = tid - f * R;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r > 0 && r - 1 < a.n_obj) {
+            v = a.mat[(r - 1) * 4 + f];
+            if (f == 0) v.w = v.w > 0.f ? v.w : (v.w < 0.f ? -2.f : -1.f);   // light e | diffuse -1 | reflective -2
+        }
+        s_mat[tid] = v;                             // miss record: colour 0, tag 0
+    }
+    auto matp = [&](int p, int f) -> float4 {       // p = 16*(k+1): byte offset of the record within a field
+        return *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s_mat) + p + f * R * 16);
+    };
+    {   // n_raw and A to VGPRs (see the header comment)
+        auto fv = [](float &x) { x = __uint_as_float(to_vgpr(__float_as_uint(x))); };
+#pragma unroll
+        for (int k = 0; k < NS; ++k) { fv(sg.g[k][0].x); fv(sg.g[k][0].y); fv(sg.g[k][0].z); fv(sg.g[k][0].w); }
+    }
+
+    const int wbase = tid & ~63;
+    const int npix = a.height * a.width;
+    const int pixel0 = blockIdx.x * BLOCK;
+    const bool in_canvas = pixel0 + tid < npix;
+    const int pc = in_canvas ? pixel0 + tid : 0;
+    const int pi = pc / a.width, pj = pc - pi * a.width;
+    const uint32_t B = (uint32_t)a.max_bounces;
+    const uint32_t stride = a.sample_stride;
+    const uint32_t gs_end = a.sample_begin + (uint32_t)a.n_samples * stride;   // first sample index beyond this launch
+    const uint32_t ctr_end = gs_end << 6;
+
+    unsigned long long segs = in_canvas ? 1 : 0;          // the fp64 primary search below
+    f3 acc = mk3(0.f, 0.f, 0.f);
+    if (in_canvas && !a.fresh) acc = mk3(a.canvas[3 * (size_t)pc + 0], a.canvas[3 * (size_t)pc + 1], a.canvas[3 * (size_t)pc + 2]);
+
+    // primary segment, once per pixel, fp64 (src/Lib.hs:41-51, :81-98)
+    const PrimaryHit ph = primary_hit_f64(a.prim, a.n_obj, a.height, a.width, a.camera_depth, pi, pj);
+    f3 cd0 = mk3((float)ph.dx, (float)ph.dy, (float)ph.dz);
+    f3 cP0 = mk3((float)(ph.t * ph.dx), (float)(ph.t * ph.dy), (float)(ph.t * ph.dz));
+    f3 ccol = mk3(1.f, 1.f, 1.f);
+    int cidxp = 16 * (ph.idx + 1); float ce = 0.f;
+    bool traced = in_canvas && ph.idx >= 0 && B >= 2;     // else every sample is black (src/Lib.hs:68,72)
+    __syncthreads();                                       // s_mat is staged
+    if (in_canvas && ph.idx >= 0) {
+        const float4 m0 = matp(cidxp, 0);
+        ce = m0.w; ccol = mk3(m0.x, m0.y, m0.z);
+        if (ce > 0.f) {                                    // the primary ray sees a light (src/Lib.hs:74)
+            for (int s = 0; s < a.n_samples; ++s) { acc.x += ce; acc.y += ce; acc.z += ce; }
+            traced = false;
+        }
+    }
+    s_pix[tid * 3 + 0] = make_float4(cP0.x, cP0.y, cP0.z, cd0.x);
+    s_pix[tid * 3 + 1] = make_float4(cd0.y, cd0.z, ccol.x, ccol.y);
+    s_pix[tid * 3 + 2] = make_float4(ccol.z, __int_as_float(cidxp), ce, 0.f);
+
+    uint64_t pre = (uint64_t)0xD256D193u * (uint64_t)(uint32_t)pc;
+    f3 o = cP0, d = cd0, thr = ccol;
+    int lastp = cidxp;
+    uint32_t ctr = (a.sample_begin << 6) | 1u;             // (global sample << 6) | segments searched on this path
+    bool alive = traced;                                   // has a path in flight
+    const PhiloxRegs pregs = philox_regs(a.seed);
+
+    auto scatter = [&](int idxp, float e, f3 din, uint32_t c1) -> f3 {
+        uint32_t r0, r1;
+        philox2x32_10_pre_v((uint32_t)(pre >> 32), (uint32_t)pre, c1, pregs, r0, r1);
+        if constexpr (SPEC) {
+            if (e < -1.5f) {                               // _reflective (src/Lib.hs:110)
+                const float4 m3 = matp(idxp, 3);
+                return scatter_specular(din, mk3(m3.y, m3.z, m3.w), u24(r0), u24(r1), NOISE_REV);
+            }
+        }
+        return scatter_diffuse_bits(matp(idxp, 1), matp(idxp, 2), matp(idxp, 3).x, r0, r1);   // src/Lib.hs:111
+    };
+    // One segment.  `draw(terminal, c1)` decides what a finished path does next
+    // and returns in c1 the counter word (sample << 6 | 0) of a restarted path.
+    auto trip = [&](auto all_alive, auto &&draw) {
+        int kp; float t;
+        closest_static<NS>(sg, o, d, lastp, kp, t);
+        const bool live = decltype(all_alive)::value ? true : alive;
+        if (!decltype(all_alive)::value) segs += live ? 1 : 0;            // phase 1 counts its trips wave-uniformly
+        const float4 m0 = matp(kp, 0);
+        // miss (tag 0, src/Lib.hs:72), light (tag e > 0, :74) or the depth cap (:68) end the path
+        bool terminal = live && ((m0.w >= 0.f) || ((ctr & 63u) + 1u >= B));
+        {                                                  // emittance * pixel (src/Lib.hs:74); max(tag, 0) is 0 unless a light
+            float E = __int_as_float(max(__float_as_int(m0.w), 0));
+            if (!decltype(all_alive)::value) E = live ? E : 0.f;
+            acc.x = fmaf(E, thr.x, acc.x);
+            acc.y = fmaf(E, thr.y, acc.y);
+            acc.z = fmaf(E, thr.z, acc.z);
+        }
+        uint32_t c1 = ctr;
+        draw(terminal, c1);                                // may clear or set `terminal` (= restart from cP0)
+        const int   idxp = terminal ? cidxp : kp;
+        const float e    = terminal ? ce : m0.w;
+        const f3    din  = terminal ? cd0 : d;
+        const f3 hp = mk3(terminal ? cP0.x : fmaf(t, d.x, o.x),         // march (src/Object.hs:151-153)
+                          terminal ? cP0.y : fmaf(t, d.y, o.y),
+                          terminal ? cP0.z : fmaf(t, d.z, o.z));
+        thr = mk3(terminal ? ccol.x : thr.x * m0.x,                       // pixel * color (src/Lib.hs:79)
+                  terminal ? ccol.y : thr.y * m0.y,
+                  terminal ? ccol.z : thr.z * m0.z);
+        d = scatter(idxp, e, din, c1);
+        o = hp; lastp = idxp; ctr = c1 + 1u;
+    };
+
+    if (alive) d = scatter(cidxp, ce, cd0, ctr - 1u);
+
+    // ---- phase 1: every lane on its own pixel --------------------------------
+    const unsigned long long everyone = __ballot(true);
+    const uint32_t next_sample = (stride << 6) - 63u;      // (ctr | 63) + next_sample = (sample + stride) << 6
+    if (__ballot(alive) == everyone) {
+        uint32_t trips = 0;                                // wave-uniform
+        do {
+            trip(std::true_type{}, [&](bool &terminal, uint32_t &c1) {
+                c1 = terminal ? (c1 | 63u) + next_sample : c1;
+            });
+            alive = ctr < ctr_end;                         // the sample the lane is on belongs to this launch
+            trips += 1;
+        } while (__ballot(alive) == everyone);
+        segs += trips;
+    }
+    // A lane that has just left phase 1 restarted a path that does not exist
+    // (its sample index is gs_end); it enters phase 2 pathless.
+
+    // ---- phase 2: the wave shares what is left -------------------------------
+    s_next[tid] = alive ? (ctr >> 6) + stride : gs_end;
+    s_acc[tid * 3 + 0] = 0.f; s_acc[tid * 3 + 1] = 0.f; s_acc[tid * 3 + 2] = 0.f;
+    __syncthreads();
+    int cur = tid;                                         // the pixel (workgroup-relative) this lane works on
+    bool dry = false;                                      // wave-uniform: no pixel has an unstarted sample
+    if (__ballot(alive) != 0ull || !dry) do {
+        trip(std::false_type{}, [&](bool &terminal, uint32_t &c1) {
+            uint32_t g = gs_end;
+            if (terminal) g = atomicAdd(&s_next[cur], stride);           // next sample of my current pixel
+            const bool want = terminal || !alive;          // lanes that need a (new) path
+            bool needy = want && !(terminal && g < gs_end);
+            while (!dry && __ballot(needy) != 0ull) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                const bool has = __hip_atomic_load(&s_next[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < gs_end;
+                const unsigned long long avail = __ballot(has);      // pixels of this wave with unstarted samples
+                if (avail == 0ull) { dry = true; break; }
+                const int v = wbase + (__ffsll((long long)avail) - 1);   // wave-uniform choice of pixel to help
+                if (needy) {
+                    g = atomicAdd(&s_next[v], stride);
+                    if (g < gs_end) {
+                        if (v != cur) {                    // hand over what was gathered, adopt pixel v
+                            atomicAdd(&s_acc[cur * 3 + 0], acc.x);
+                            atomicAdd(&s_acc[cur * 3 + 1], acc.y);
+                            atomicAdd(&s_acc[cur * 3 + 2], acc.z);
+                            acc = mk3(0.f, 0.f, 0.f);
+                            cur = v;
+                            const float4 p0 = s_pix[v * 3 + 0], p1 = s_pix[v * 3 + 1], p2 = s_pix[v * 3 + 2];
+                            cP0 = mk3(p0.x, p0.y, p0.z); cd0 = mk3(p0.w, p1.x, p1.y); ccol = mk3(p1.z, p1.w, p2.x);
+                            cidxp = __float_as_int(p2.y); ce = p2.z;
+                            pre = (uint64_t)0xD256D193u * (uint64_t)(uint32_t)(pixel0 + v);
+                        }
+                        needy = false;
+                    }
+                }
+            }
+            alive = !want || !needy;                       // path continues, or a sample was drawn
+            terminal = want && !needy;                     // restart from the (current) pixel's primary hit
+            if (terminal) c1 = g << 6;
+        });
+    } while (__ballot(alive) != 0ull || !dry);
+
+    atomicAdd(&s_acc[cur * 3 + 0], acc.x);
+    atomicAdd(&s_acc[cur * 3 + 1], acc.y);
+    atomicAdd(&s_acc[cur * 3 + 2], acc.z);
+    __syncthreads();
+    if (in_canvas) {
+        a.canvas[3 * (size_t)pc + 0] = s_acc[tid * 3 + 0];
+        a.canvas[3 * (size_t)pc + 1] = s_acc[tid * 3 + 1];
+        a.canvas[3 * (size_t)pc + 2] = s_acc[tid * 3 + 2];
+    }
+
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) segs += __shfl_down(segs, off, 64);
+    if ((tid & 63) == 0 && segs) atomicAdd(a.segments, segs);
+}
+
 template <int NS>
 static hipError_t launch_trace_ns(TraceArgs a, const float4 *geom_host, bool reuse, bool spec, bool steal,
                                   hipStream_t s)
@@ -542,6 +826,15 @@ static hipError_t launch_trace_ns(TraceArgs a, const float4 *geom_host, bool reu
     }
     const int npix = a.height * a.width;
     const dim3 grid((npix + BLOCK - 1) / BLOCK), block(BLOCK);
+#if !(PT_EXP & 128)
+    if constexpr (NS > 0) {
+        if (steal && reuse) {
+            if (spec) hipLaunchKernelGGL((trace_static_kernel<NS, true>), grid, block, 0, s, a, sg);
+            else      hipLaunchKernelGGL((trace_static_kernel<NS, false>), grid, block, 0, s, a, sg);
+            return hipGetLastError();
+        }
+    }
+#endif
     if constexpr (NS >= 0) {
         if (steal && reuse) {
             if (spec) hipLaunchKernelGGL((trace_steal_kernel<NS, true>), grid, block, 0, s, a, sg, a.geom);
