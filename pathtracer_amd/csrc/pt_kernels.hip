@@ -625,7 +625,9 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_static_kernel(TraceArgs a, 
     __shared__ uint32_t s_next[BLOCK];              // per pixel: next global sample index not started
     __shared__ float4   s_pix[BLOCK * 3];           // per pixel: P0, d0, colour0, idx0, e0
     __shared__ float    s_acc[BLOCK * 3];           // per pixel: radiance gathered in phase 2
+    __shared__ unsigned long long s_segs;           // the workgroup's segment count
     const int tid = threadIdx.x;
+    if (tid == 0) s_segs = 0;
     if (tid < 4 * R) {
         const int f = tid / R, r = tid - f * R;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -793,16 +795,19 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_static_kernel(TraceArgs a, 
     atomicAdd(&s_acc[cur * 3 + 0], acc.x);
     atomicAdd(&s_acc[cur * 3 + 1], acc.y);
     atomicAdd(&s_acc[cur * 3 + 2], acc.z);
+    // one global atomic per workgroup for the segment counter: 32,400 same-address
+    // atomics (one per wave) serialise in L2 when a short launch's workgroups
+    // retire together
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) segs += __shfl_down(segs, off, 64);
+    if ((tid & 63) == 0 && segs) atomicAdd(&s_segs, segs);
     __syncthreads();
     if (in_canvas) {
         a.canvas[3 * (size_t)pc + 0] = s_acc[tid * 3 + 0];
         a.canvas[3 * (size_t)pc + 1] = s_acc[tid * 3 + 1];
         a.canvas[3 * (size_t)pc + 2] = s_acc[tid * 3 + 2];
     }
-
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) segs += __shfl_down(segs, off, 64);
-    if ((tid & 63) == 0 && segs) atomicAdd(a.segments, segs);
+    if (tid == 0 && s_segs) atomicAdd(a.segments, s_segs);
 }
 
 template <int NS>
