@@ -45,7 +45,7 @@ constexpr int64_t MAX_GLOBAL_SAMPLES = (int64_t)1 << 26;   // sample index share
 constexpr int     MAX_BOUNCES = 64;
 constexpr int     MAX_OBJECTS = 65536;
 constexpr int     MAX_SAMPLES_PER_LAUNCH = 4096;
-constexpr int     SEG_SLOTS = 1024;
+constexpr int     SEG_SLOTS = 64;                 // pt_reset epochs before the ring is cleared
 
 int fail(pt_ctx *c, int status, const std::string &msg)
 {
@@ -205,10 +205,10 @@ int pt_create(pt_ctx **out, const pt_params *params)
     c->stream = c->own_stream;
     const size_t cbytes = npix(c) * 3 * sizeof(float);
     if ((e = hipMalloc((void **)&c->d_canvas, cbytes)) != hipSuccess) return bail("hipMalloc(canvas)", e);
-    if ((e = hipMalloc((void **)&c->d_segments, SEG_SLOTS * sizeof(unsigned long long))) != hipSuccess)
+    if ((e = hipMalloc((void **)&c->d_segments, (size_t)SEG_SLOTS * SEG_EPOCH * sizeof(unsigned long long))) != hipSuccess)
         return bail("hipMalloc(segments)", e);
     if ((e = hipMemsetAsync(c->d_canvas, 0, cbytes, c->stream)) != hipSuccess) return bail("hipMemset", e);
-    if ((e = hipMemsetAsync(c->d_segments, 0, SEG_SLOTS * sizeof(unsigned long long), c->stream)) != hipSuccess)
+    if ((e = hipMemsetAsync(c->d_segments, 0, (size_t)SEG_SLOTS * SEG_EPOCH * sizeof(unsigned long long), c->stream)) != hipSuccess)
         return bail("hipMemset", e);
     if ((e = hipEventCreate(&c->ev0)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipEventCreate(&c->ev1)) != hipSuccess) return bail("hipEventCreate", e);
@@ -293,7 +293,7 @@ int pt_trace(pt_ctx *c, int32_t iters)
     while (left > 0) {
         const int32_t n = left < MAX_SAMPLES_PER_LAUNCH ? left : MAX_SAMPLES_PER_LAUNCH;
         TraceArgs a{};
-        a.canvas = c->d_canvas; a.segments = c->d_segments + c->seg_slot;
+        a.canvas = c->d_canvas; a.segments = c->d_segments + (size_t)c->seg_slot * SEG_EPOCH;
         a.fresh = c->canvas_stale ? 1 : 0;           // the canvas is logically zero: do not read it
         a.geom = c->d_geom; a.mat = c->d_mat; a.prim = c->d_prim;
         a.camera_depth = c->p.camera_depth;
@@ -336,7 +336,7 @@ int pt_reset(pt_ctx *c)
     if (int s = check_ctx(c)) return s;
     c->canvas_stale = true;
     if (++c->seg_slot == SEG_SLOTS) {
-        PT_HIP(c, hipMemsetAsync(c->d_segments, 0, SEG_SLOTS * sizeof(unsigned long long), c->stream));
+        PT_HIP(c, hipMemsetAsync(c->d_segments, 0, (size_t)SEG_SLOTS * SEG_EPOCH * sizeof(unsigned long long), c->stream));
         c->seg_slot = 0;
     }
     c->samples_done = 0;
@@ -418,9 +418,11 @@ int pt_segments(pt_ctx *c, uint64_t *out)
 {
     if (int s = check_ctx(c)) return s;
     if (!out) return fail(c, PT_ERR_INVALID, "pt_segments: null output");
-    unsigned long long v = 0;
-    PT_HIP(c, hipMemcpyAsync(&v, c->d_segments + c->seg_slot, sizeof v, hipMemcpyDeviceToHost, c->stream));
+    unsigned long long lanes[SEG_EPOCH];
+    PT_HIP(c, hipMemcpyAsync(lanes, c->d_segments + (size_t)c->seg_slot * SEG_EPOCH, sizeof lanes, hipMemcpyDeviceToHost, c->stream));
     PT_HIP(c, hipStreamSynchronize(c->stream));
+    unsigned long long v = 0;
+    for (int l = 0; l < SEG_LANES; ++l) v += lanes[l * SEG_LANE_STRIDE];
     *out = (uint64_t)v;
     return PT_OK;
 }

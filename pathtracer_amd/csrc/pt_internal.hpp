@@ -17,9 +17,14 @@ template <int NS> struct StaticGeom {
     float4 g[NS > 0 ? NS : 1][3];
 };
 
+// Segment counter layout: SEG_LANES 64-bit counters per epoch, one per 128-byte line.
+constexpr int SEG_LANES = 64;
+constexpr int SEG_LANE_STRIDE = 16;                 // in counters (128 bytes)
+constexpr int SEG_EPOCH = SEG_LANES * SEG_LANE_STRIDE;
+
 struct TraceArgs {
     float              *canvas;        // H*W*3 fp32 radiance sums, (i*W+j)*3+k
-    unsigned long long *segments;      // closest-hit searches executed
+    unsigned long long *segments;      // closest-hit searches executed: SEG_LANES counters, SEG_LANE_STRIDE apart
     const float4       *geom;          // n_obj * 3 float4   (dynamic path)
     const float4       *mat;           // n_obj * 4 float4
     const double       *prim;          // n_obj * PRIM_DOUBLES
