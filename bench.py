@@ -9,6 +9,10 @@ resident in HBM:
     indices) -> [N > 1: ONE RCCL all-reduce (sum) of the fp32 canvas over xGMI]
     -> fused RGB8 output kernel on rank 0.
 The total work per step is fixed as N grows, so "scaling" is "strong".
+For N > 1 the frames are double-buffered (pathtracer_amd.distributed.
+PipelinedFrames): frame k's all-reduce and output run on their own streams
+while frame k+1 is traced into the other canvas; the timed region ends with a
+full drain, so all K frames are complete (traced, reduced, quantised) in it.
 
 value = closest-hit searches executed by all ranks in the timed steps / wall
 time (Mrays/s, a ray = one closestObjectTo, src/Lib.hs:81).  The searches are
@@ -78,6 +82,8 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--no-primary-reuse", action="store_true")
     ap.add_argument("--no-steal", action="store_true", help="PT_FLAG_NO_STEAL: strict per-lane sample order")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="N > 1: all-reduce and output in line with the trace instead of overlapped with the next frame")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -90,7 +96,7 @@ def main():
 
     import torch
     import pathtracer_amd as pa
-    from pathtracer_amd.distributed import allreduce_canvas, canvas_tensor, shard_samples
+    from pathtracer_amd.distributed import PipelinedFrames, allreduce_canvas, canvas_tensor, shard_samples
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: libpt has no CPU path")
@@ -106,17 +112,29 @@ def main():
     my_spp, s_off, s_stride = shard_samples(args.spp, rank, world)
     P = pa.Params(args.height, args.width, args.camera_depth, args.spp, args.bounces)
     flags = (pa.PT_FLAG_NO_PRIMARY_REUSE if args.no_primary_reuse else 0) | (pa.PT_FLAG_NO_STEAL if args.no_steal else 0)
-    r = pa.Renderer(P, pa.objects, seed=0, device=local_rank, sample_offset=s_off, sample_stride=s_stride,
-                    flags=flags)
-    stream = torch.cuda.current_stream()
-    r.set_stream(stream.cuda_stream)          # kernels, all-reduce and events share torch's stream
+    # An explicit stream: libpt cannot be pointed at the legacy null stream, and
+    # the all-reduce must be ordered after the trace kernel on the SAME stream.
+    stream = torch.cuda.Stream()
+    torch.cuda.set_stream(stream)
+    pipelined = dist is not None and not args.no_pipeline
+    rs = [pa.Renderer(P, pa.objects, seed=0, device=local_rank, sample_offset=s_off, sample_stride=s_stride,
+                      flags=flags) for _ in range(2 if pipelined else 1)]
+    for q in rs:
+        q.set_stream(stream.cuda_stream)      # kernels, all-reduce and events share this stream
+    r = rs[0]
 
-    # the context's canvas as a torch tensor (no copy), for the all-reduce
-    canvas = canvas_tensor(r, local_rank)
-    rgb = torch.empty(args.height * args.width * 3, dtype=torch.uint8, device="cuda")
-
+    # the contexts' canvases as torch tensors (no copy), for the all-reduce
+    canvases = [canvas_tensor(q, local_rank) for q in rs]
+    canvas = canvases[0]
+    rgbs = [torch.empty(args.height * args.width * 3, dtype=torch.uint8, device="cuda") for _ in rs]
+    rgb = rgbs[0]
+    pipe = PipelinedFrames(rs, canvases, rgbs, rank=rank, spp_total=args.spp, my_spp=my_spp,
+                           mode=pa.PT_RGB8_MEAN_CLAMP, dist=dist) if pipelined else None
 
     def step():
+        if pipe is not None:
+            pipe.step()
+            return
         r.reset()
         r.trace(my_spp)
         if dist is not None:
@@ -132,6 +150,8 @@ def main():
     for _ in range(max(args.warmup, 1)):       # at least one, to count a step's segments
         step()
     fence()
+    if pipe is not None:
+        r = rs[(pipe.k - 1) & 1]               # the context of the last frame: its counter holds one step
     segs_step = torch.tensor([r.segments], dtype=torch.float64, device="cuda")
 
     fence()
@@ -187,7 +207,9 @@ def main():
                        "segments_per_step": int(total_segs_step),
                        "paths_per_step": args.height * args.width * args.spp,
                        "primary_reuse": not args.no_primary_reuse,
-                       "parallelism": f"sample-split x{world}"},
+                       "parallelism": f"sample-split x{world}",
+                       "frame_pipeline": "double-buffered: all-reduce + output of frame k overlap the trace of "
+                                         "frame k+1" if pipe is not None else "none"},
             "roofline": {"bound": "valu", "achieved": round(achieved, 3), "peak": FP32_VALU_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / FP32_VALU_PEAK_TFLOPS, 4),
                          "traffic": traffic,
@@ -201,7 +223,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.height, args.width, args.camera_depth, args.bounces, threads)
         print(json.dumps(out), flush=True)
 
-    r.close()
+    for q in rs:
+        q.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

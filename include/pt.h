@@ -155,6 +155,13 @@ int pt_canvas_device_ptr(pt_ctx *ctx, void **dptr, size_t *bytes);
 int pt_set_stream(pt_ctx *ctx, void *hip_stream);
 int pt_synchronize(pt_ctx *ctx);
 int pt_rgb8_device(pt_ctx *ctx, void *d_out, int32_t mode, int64_t samples_override);
+/* The same output kernel (Conversion.repa3ToImage, src/Conversion.hs:22-28)
+ * launched on a caller-named hipStream_t instead of the context's stream, for
+ * hosts that overlap frame k's output (and its all-reduce) with the tracing of
+ * frame k+1 on another context -- the pull-next-frame loop of app/Web.hs:42-65.
+ * The caller orders `hip_stream` after the trace and the all-reduce (events);
+ * fails with PT_ERR_INVALID if nothing was traced since pt_reset. */
+int pt_rgb8_device_on(pt_ctx *ctx, void *d_out, int32_t mode, int64_t samples_override, void *hip_stream);
 
 /* Host -> device canvas write, for the quantiser's parity test and for
  * checkpoint/resume of (sum, samples_done). */

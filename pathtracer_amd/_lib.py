@@ -73,6 +73,7 @@ SIGNATURES = {
     "pt_set_stream": (C.c_int, [_P, _P]),
     "pt_synchronize": (C.c_int, [_P]),
     "pt_rgb8_device": (C.c_int, [_P, _P, C.c_int32, C.c_int64]),
+    "pt_rgb8_device_on": (C.c_int, [_P, _P, C.c_int32, C.c_int64, _P]),
     "pt_write_sum_f32": (C.c_int, [_P, _P, C.c_int64]),
     "pt_dev_diffuse": (C.c_int, [_P, C.c_int32, _P, _P, _P]),
     "pt_dev_specular": (C.c_int, [_P, C.c_int32, _P, _P, _P, C.c_float, _P]),

@@ -363,7 +363,7 @@ int pt_read_sum(pt_ctx *c, double *out)
     return PT_OK;
 }
 
-int pt_rgb8_device(pt_ctx *c, void *d_out, int32_t mode, int64_t samples_override)
+static int rgb8_on(pt_ctx *c, void *d_out, int32_t mode, int64_t samples_override, hipStream_t stream)
 {
     if (int s = check_ctx(c)) return s;
     if (!d_out) return fail(c, PT_ERR_INVALID, "pt_rgb8_device: null output");
@@ -372,8 +372,23 @@ int pt_rgb8_device(pt_ctx *c, void *d_out, int32_t mode, int64_t samples_overrid
     if (int s = materialise_canvas(c)) return s;
     const int64_t ns = samples_override > 0 ? samples_override : c->samples_done;
     const double inv = ns > 0 ? 1.0 / (double)ns : 0.0;
-    PT_HIP(c, launch_rgb8(c->d_canvas, (uint8_t *)d_out, c->p.height, c->p.width, mode, inv, c->stream));
+    PT_HIP(c, launch_rgb8(c->d_canvas, (uint8_t *)d_out, c->p.height, c->p.width, mode, inv, stream));
     return PT_OK;
+}
+
+int pt_rgb8_device(pt_ctx *c, void *d_out, int32_t mode, int64_t samples_override)
+{
+    if (int s = check_ctx(c)) return s;
+    return rgb8_on(c, d_out, mode, samples_override, c->stream);
+}
+
+int pt_rgb8_device_on(pt_ctx *c, void *d_out, int32_t mode, int64_t samples_override, void *hip_stream)
+{
+    if (int s = check_ctx(c)) return s;
+    if (!hip_stream) return fail(c, PT_ERR_INVALID, "pt_rgb8_device_on: null stream");
+    if (c->canvas_stale)        // the lazy zero-fill would run on the context's stream, unordered with hip_stream
+        return fail(c, PT_ERR_INVALID, "pt_rgb8_device_on: nothing traced since pt_reset");
+    return rgb8_on(c, d_out, mode, samples_override, (hipStream_t)hip_stream);
 }
 
 int pt_read_rgb8(pt_ctx *c, uint8_t *out, int32_t mode)

@@ -41,3 +41,62 @@ def canvas_tensor(renderer, device_index: int):
         __cuda_array_interface__ = {"shape": (nbytes // 4,), "typestr": "<f4", "data": (ptr, False),
                                     "version": 2, "strides": None}
     return torch.as_tensor(_Canvas(), device=torch.device("cuda", device_index))
+
+
+class PipelinedFrames:
+    """Frame pipeline for the multi-GPU bench and for progressive serving
+    (the pull-next-frame contract of app/Web.hs:42-65): frame k is traced into
+    canvas k % 2 while frame k-1's all-reduce (RCCL's own stream) and RGB8
+    output (a side stream) are still in flight, so the collective's time is
+    hidden behind the next frame's kernel instead of added to it.  Every frame
+    is still one pt_reset + pt_trace + ONE all-reduce + the output kernel; only
+    their placement on streams changes.  `drain()` waits for everything.
+
+    renderers: two contexts on this rank's GPU with identical parameters and
+    scene; canvases: their device canvases as torch tensors (canvas_tensor);
+    rgb: two device uint8 buffers (rank 0 only, else None).
+    """
+
+    def __init__(self, renderers, canvases, rgb, *, rank, spp_total, my_spp, mode, dist=None):
+        import torch
+        self.torch = torch
+        self.r, self.cv, self.rgb = renderers, canvases, rgb
+        self.rank, self.spp_total, self.my_spp, self.mode, self.dist = rank, spp_total, my_spp, mode, dist
+        self.main = torch.cuda.current_stream()
+        if self.main.cuda_stream == 0:
+            raise ValueError("PipelinedFrames needs an explicit torch stream as the current stream: libpt cannot "
+                             "be pointed at the legacy null stream (pt_set_stream(NULL) = the context's own stream)")
+        self.side = torch.cuda.Stream()
+        for r in renderers:
+            r.set_stream(self.main.cuda_stream)
+        self.done = [None, None]          # event: canvas k % 2 is free again
+        self.k = 0
+
+    def step(self):
+        torch = self.torch
+        b = self.k & 1
+        r, cv = self.r[b], self.cv[b]
+        if self.done[b] is not None:
+            self.main.wait_event(self.done[b])           # frame k-2's output has left this canvas
+        r.reset()
+        r.trace(self.my_spp)
+        work = None
+        if self.dist is not None:
+            work = self.dist.all_reduce(cv, op=self.dist.ReduceOp.SUM, async_op=True)   # ordered after the trace
+        traced = torch.cuda.Event()
+        traced.record(self.main)
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(traced)
+            if work is not None:
+                work.wait()                               # the side stream waits for the collective
+            if self.rank == 0:
+                r.rgb8_device_on(self.rgb[b].data_ptr(), self.side.cuda_stream, self.mode, self.spp_total)
+            ev = torch.cuda.Event()
+            ev.record(self.side)
+        self.done[b] = ev
+        self.k += 1
+        return b
+
+    def drain(self):
+        self.side.synchronize()
+        self.main.synchronize()

@@ -112,6 +112,10 @@ class Renderer:
     def rgb8_device(self, d_out: int, mode: int = _lib.PT_RGB8_REFERENCE, samples: int = 0):
         check(lib.pt_rgb8_device(self._ctx, C.c_void_p(d_out), mode, samples), self._ctx)
 
+    def rgb8_device_on(self, d_out: int, hip_stream: int, mode: int = _lib.PT_RGB8_REFERENCE, samples: int = 0):
+        """pt_rgb8_device on a caller-named stream (the caller orders it)."""
+        check(lib.pt_rgb8_device_on(self._ctx, C.c_void_p(d_out), mode, samples, C.c_void_p(hip_stream)), self._ctx)
+
     def set_timing(self, on: bool = True):
         check(lib.pt_set_timing(self._ctx, 1 if on else 0), self._ctx)
 

@@ -1,0 +1,76 @@
+"""PipelinedFrames (pathtracer_amd/distributed.py): the double-buffered frame
+loop of the multi-GPU bench.  Frame k's output runs on a side stream while frame
+k+1 is traced into the other canvas; every frame must still equal the in-line
+reset -> trace -> output sequence byte for byte, and the oracle's quantiser
+(Conversion.repa3ToImage, src/Conversion.hs:22-28) of the same sums."""
+import numpy as np
+import pytest
+
+import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def test_pipelined_frames_equal_inline_frames():
+    import torch
+    import pathtracer_amd as pa
+    from pathtracer_amd.distributed import PipelinedFrames, canvas_tensor
+
+    H, W, SPP, B = 160, 96, 6, 6
+    P = pa.Params(H, W, 500.0, SPP, B)
+    with pa.Renderer(P, seed=3) as ref:
+        ref.trace(SPP)
+        want = ref.read_rgb8(pa.PT_RGB8_MEAN_CLAMP)
+        want_ref_mode = ref.read_rgb8(pa.PT_RGB8_REFERENCE)
+        sums = ref.read_sum_f32()
+    assert np.array_equal(want_ref_mode, O.repa3_to_image(O.params(H, W, 500.0, B), sums.astype(np.float64)))
+
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        rs = [pa.Renderer(P, seed=3) for _ in range(2)]
+        cvs = [canvas_tensor(q, 0) for q in rs]
+        rgbs = [torch.zeros(H * W * 3, dtype=torch.uint8, device="cuda") for _ in rs]
+        pipe = PipelinedFrames(rs, cvs, rgbs, rank=0, spp_total=SPP, my_spp=SPP, mode=pa.PT_RGB8_MEAN_CLAMP, dist=None)
+        seen = []
+        for k in range(7):
+            b = pipe.step()
+            if k >= 1:                                     # read frame k-1 while frame k is in flight
+                pipe.done[1 - b].synchronize()
+                seen.append(rgbs[1 - b].cpu().numpy().reshape(W, H, 3).copy())
+        pipe.drain()
+        seen.append(rgbs[b].cpu().numpy().reshape(W, H, 3).copy())
+        for q in rs:
+            q.close()
+    assert len(seen) == 7
+    for img in seen:
+        assert np.array_equal(img, want)
+
+
+def test_pipeline_refuses_the_null_stream():
+    import torch
+    import pathtracer_amd as pa
+    from pathtracer_amd.distributed import PipelinedFrames
+    if torch.cuda.current_stream().cuda_stream != 0:
+        pytest.skip("the current stream is not the null stream here")
+    P = pa.Params(32, 32, 500.0, 1, 4)
+    with pa.Renderer(P) as a, pa.Renderer(P) as b:
+        with pytest.raises(ValueError):
+            PipelinedFrames([a, b], [None, None], [None, None], rank=0, spp_total=1, my_spp=1, mode=0, dist=None)
+
+
+def test_rgb8_on_stream_needs_a_traced_canvas():
+    import torch
+    import pathtracer_amd as pa
+    P = pa.Params(32, 32, 500.0, 1, 4)
+    s = torch.cuda.Stream()
+    out = torch.zeros(32 * 32 * 3, dtype=torch.uint8, device="cuda")
+    with pa.Renderer(P) as r:
+        r.trace(1)
+        r.reset()
+        with pytest.raises(pa.PtError):
+            r.rgb8_device_on(out.data_ptr(), s.cuda_stream)        # nothing traced since pt_reset: lazy zero-fill pending
+        r.trace(1)
+        r.synchronize()
+        r.rgb8_device_on(out.data_ptr(), s.cuda_stream)
+        s.synchronize()
+        assert np.array_equal(out.cpu().numpy().reshape(32, 32, 3), r.read_rgb8())
