@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""summarise_pmc.py <tag> [kernel-substring]: per-launch means of the PMC passes
+that profiles/run_pmc.sh left under gpurun_out/<tag>/, plus the derived figures
+DESIGN.md quotes.  Writes profiles/<tag>_pmc_summary.txt and copies the
+kernel-trace stats to profiles/<tag>_kernel_stats.csv."""
+import csv
+import glob
+import os
+import shutil
+import sys
+
+tag = sys.argv[1]
+kern = sys.argv[2] if len(sys.argv) > 2 else "trace_static_kernel<4, false>"
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(root, "gpurun_out", tag)
+lines = [f"# {tag}: rocprofv3 PMC passes over `python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline` (profiles/run_pmc.sh {tag})",
+         f"# per-launch means over the dispatches of {kern}; default scene 1920x1080, 1024 spp, maxBounces 8"]
+C = {}
+for p in sorted(glob.glob(os.path.join(src, "pmc*"))):
+    if not os.path.isdir(p):
+        continue
+    for f in glob.glob(os.path.join(p, "*", "*_counter_collection.csv")):
+        acc = {}
+        for row in csv.DictReader(open(f)):
+            if kern in row["Kernel_Name"]:
+                acc.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+        for k, v in sorted(acc.items()):
+            C[k] = sum(v) / len(v)
+            lines.append(f"{os.path.basename(p):5s} {k:26s} n={len(v)} mean={C[k]:.6g}")
+stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))
+avg_ms = None
+if stats:
+    shutil.copy(stats[0], os.path.join(root, "profiles", f"{tag}_kernel_stats.csv"))
+    for row in csv.DictReader(open(stats[0])):
+        if kern in row["Name"]:
+            avg_ms = float(row["AverageNs"]) / 1e6
+            calls = int(row["Calls"])
+lines.append("")
+lines.append("# derived")
+SEGS = 6551447147
+if avg_ms:
+    lines.append(f"kernel-trace average duration: {avg_ms:.3f} ms over {calls} calls")
+    lines.append(f"algorithmic rate: 97 flop x {SEGS} segments / {avg_ms:.3f} ms = {97 * SEGS / avg_ms / 1e9:.2f} TFLOP/s = "
+                 f"{97 * SEGS / avg_ms / 1e9 / 157.3:.4f} of 157.3")
+g = C.get
+if g("SQ_INSTS_VALU"):
+    lines.append(f"VALU wave-instructions per segment-trip (64 lanes): {g('SQ_INSTS_VALU') / (SEGS / 64):.1f}")
+if g("SQ_THREAD_CYCLES_VALU") and g("SQ_ACTIVE_INST_VALU"):
+    lines.append(f"lane utilisation SQ_THREAD_CYCLES_VALU/(64*SQ_ACTIVE_INST_VALU): {g('SQ_THREAD_CYCLES_VALU') / (64 * g('SQ_ACTIVE_INST_VALU')):.3f}")
+if g("SQ_LDS_BANK_CONFLICT") and g("SQ_LDS_IDX_ACTIVE"):
+    lines.append(f"LDS bank-conflict share SQ_LDS_BANK_CONFLICT/SQ_LDS_IDX_ACTIVE: {g('SQ_LDS_BANK_CONFLICT') / g('SQ_LDS_IDX_ACTIVE'):.3f}")
+if g("GRBM_GUI_ACTIVE") and avg_ms:
+    cyc = g("GRBM_GUI_ACTIVE") / 8
+    lines.append(f"kernel cycles GRBM_GUI_ACTIVE/8 XCDs: {cyc:.4g} -> {cyc / avg_ms / 1e6:.2f} GHz")
+    if g("SQ_INSTS_VALU"):
+        lines.append(f"VALU issue rate: {g('SQ_INSTS_VALU') / 1024 / cyc:.3f} wave-instructions per cycle per SIMD")
+    if g("SQ_WAVE_CYCLES"):
+        lines.append(f"mean waves per SIMD 4*SQ_WAVE_CYCLES/(1024*cycles): {4 * g('SQ_WAVE_CYCLES') / 1024 / cyc:.2f}")
+if g("SQ_INSTS_SALU") and g("SQ_INSTS_VALU"):
+    lines.append(f"SALU/VALU instruction ratio: {g('SQ_INSTS_SALU') / g('SQ_INSTS_VALU'):.3f}")
+if g("TCC_EA0_RDREQ_sum") is not None and g("TCC_EA0_WRREQ_sum") is not None:
+    rd = g("TCC_EA0_RDREQ_sum") * 64 * 2
+    wr = g("TCC_EA0_WRREQ_sum") * 64
+    lines.append(f"HBM traffic: reads TCC_EA0_RDREQ_sum*64 B*2 = {rd / 1e6:.1f} MB (gfx950 tallies 128-B read requests at 64 B, "
+                 f"MI355X_MICROARCH.md HBM); writes TCC_EA0_WRREQ_sum*64 B = {wr / 1e6:.1f} MB; total {(rd + wr) / 1e6:.1f} MB per launch; "
+                 f"algorithmic: one 24.9-MB canvas write (bench frames start from a reset canvas and skip the read)")
+    import json
+    json.dump({"tag": tag, "height": 1920, "width": 1080, "spp": 1024, "bytes_per_launch": int(rd + wr),
+               "source": f"profiles/{tag}_pmc_summary.txt (TCC_EA0_RDREQ_sum*128 + TCC_EA0_WRREQ_sum*64)"},
+              open(os.path.join(root, "profiles", "hbm_traffic.json"), "w"))
+out = os.path.join(root, "profiles", f"{tag}_pmc_summary.txt")
+open(out, "w").write("\n".join(lines) + "\n")
+print("\n".join(lines))
