@@ -85,11 +85,38 @@ SIGNATURES = {
 }
 
 
+def _share_torch_hip_runtime():
+    """One HIP runtime per process.  The PyTorch-ROCm wheel bundles its own
+    libamdhip64 and asks for it by the unversioned name, which the loader does
+    not match against a copy that libpt.so pulled in first from /opt/rocm by its
+    soname: torch would then start a SECOND runtime and find no device
+    ("no ROCm-capable device is detected").  Loading the wheel's copy first
+    makes both orders resolve to the same object (libpt.so's NEEDED entry matches
+    it by soname, torch's by path).  No torch import happens here."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load(path=LIB_PATH):
     if not os.path.exists(path):
         raise ImportError(
             f"{path} not found: build it with `make -C pathtracer_amd/csrc` "
             "(or __graft_entry__.build()); pathtracer_amd has no fallback path")
+    _share_torch_hip_runtime()
     lib = C.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)       # AttributeError if the ABI lost a symbol

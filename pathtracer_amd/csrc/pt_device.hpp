@@ -226,8 +226,11 @@ __device__ __forceinline__ float distance_from(float4 g0, float4 g1, float4 g2, 
 {
     const float num = fmaf(-o.z, g0.z, fmaf(-o.y, g0.y, fmaf(-o.x, g0.x, g0.w)));
     const float den = fmaf(v.z, g1.z, fmaf(v.y, g1.y, v.x * g1.x));
-    const float t = num * __builtin_amdgcn_rcpf(den);
-    bool ok = (t > 0.0f) && (t < __builtin_inff());          // guard, src/Object.hs:159
+    // the trace kernel's form (closest_static): the -denorm_min addend turns t = +0
+    // negative and leaves every other value as it rounds, so that one unsigned
+    // compare of the bits is the guard 0 < t < Inf (src/Object.hs:159)
+    const float t = fmaf(num, __builtin_amdgcn_rcpf(den), -__builtin_bit_cast(float, 1u));
+    bool ok = __float_as_uint(t) < 0x7f800000u;
     if (g1.w != __builtin_inff()) {                           // Disk, src/Object.hs:165-171
         const f3 d = mk3(fmaf(t, v.x, o.x) - g2.x, fmaf(t, v.y, o.y) - g2.y, fmaf(t, v.z, o.z) - g2.z);
         ok = ok && (dot3(d, d) < g1.w);

@@ -600,16 +600,20 @@ template <int NS>
 __device__ __forceinline__ void closest_static(const StaticGeom<NS> &sg, f3 o, f3 v, int lastp, int &bestp,
                                                float &best_t)
 {
-    // keys as in test_object_key: bits(t) - 1, valid iff below KEY_LIMIT, strict '<' keeps the earlier object
-    uint32_t best_key = KEY_LIMIT;
+    // The bits of t order the candidates as unsigned integers: finite positive t
+    // below bits(+Inf); t <= -0, NaN and +Inf at or above it.  t = +0 alone would
+    // pass (0 < t is strict, src/Object.hs:159), so the product is formed as
+    // fma(num, 1/den, -denorm_min): +0 becomes negative, every other value is
+    // unchanged by the rounding.  A strict '<' keeps the earlier object on ties.
+    uint32_t best_key = 0x7f800000u;
     bestp = 0;
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
         const float4 g0 = sg.g[k][0], g1 = sg.g[k][1], g2 = sg.g[k][2];
         const float on  = fmaf(o.z, g0.z, fmaf(o.y, g0.y, o.x * g0.x));
         const float den = fmaf(v.z, g1.z, fmaf(v.y, g1.y, v.x * g1.x));
-        const float t = (g0.w - on) * __builtin_amdgcn_rcpf(den);
-        const uint32_t key = __float_as_uint(t) - 1u;
+        const float t = fmaf(g0.w - on, __builtin_amdgcn_rcpf(den), -__builtin_bit_cast(float, 1u));
+        const uint32_t key = __float_as_uint(t);
         bool ok = (key < best_key) & (16 * (k + 1) != lastp);     // 0 < t < best, not _lastStruck (src/Lib.hs:86-90)
         if (g1.w != __builtin_inff()) {                            // wave-uniform: Disk (src/Object.hs:165-171)
             const float dx = fmaf(t, v.x, o.x) - g2.x;
@@ -620,7 +624,7 @@ __device__ __forceinline__ void closest_static(const StaticGeom<NS> &sg, f3 o, f
         bestp = ok ? 16 * (k + 1) : bestp;
         best_key = ok ? key : best_key;
     }
-    best_t = __uint_as_float(best_key + 1u);
+    best_t = __uint_as_float(best_key);
 }
 
 // One wave per workgroup: the finest dispatch grain, no barriers that wait on
