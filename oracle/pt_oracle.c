@@ -310,7 +310,10 @@ void o_philox2x32_10(uint32_t c0, uint32_t c1, uint32_t key, uint32_t out[2])
     out[0] = c0; out[1] = c1;
 }
 
-static double u24(uint32_t x) { return (double)(x >> 8) * (1.0 / 16777216.0); }
+/* the device's two uniforms of a bounce (pathtracer_amd/csrc/pt_device.hpp): low 21 bits
+ * of the first Philox word for theta, low 23 bits of the second for phi */
+static double u_theta(uint32_t x) { return (double)(x & 0x1fffffu) * (1.0 / 2097152.0); }
+static double u_phi(uint32_t x)   { return (double)(x & 0x7fffffu) * (1.0 / 8388608.0); }
 
 /* ------------------------------------------------------------------------ */
 /* Lib.hs                                                                    */
@@ -402,8 +405,8 @@ static void draw2(draw_state *d, double *u1, double *u2)
     } else {
         uint32_t out[2];
         o_philox2x32_10(d->pixel, (uint32_t)((d->sample << 6) | (uint32_t)d->bounce), d->seed, out);
-        *u1 = u24(out[0]);
-        *u2 = u24(out[1]);
+        *u1 = u_theta(out[0]);
+        *u2 = u_phi(out[1]);
     }
 }
 

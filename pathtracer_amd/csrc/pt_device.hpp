@@ -121,12 +121,15 @@ __device__ __forceinline__ void philox2x32_10_pre(uint32_t hi0, uint32_t lo0, ui
     o0 = c0; o1 = c1;
 }
 
-// 24-bit uniform in [0,1): exactly representable in fp32 and fp64, so the
-// device and the oracle's Philox mode see the same number.
-__device__ __forceinline__ float u24(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }
-// u24(x) * scale with the two multiplies folded into one: 2^-24 is a power of
-// two, so (k * 2^-24) * c and k * (c * 2^-24) round identically.
-__device__ __forceinline__ float u24_scaled(uint32_t x, float scale) { return (float)(x >> 8) * (scale * (1.0f / 16777216.0f)); }
+// The two uniforms of a bounce, taken from the low bits of the two Philox words:
+//   u1 = (r0 & 0x1fffff) / 2^21   (theta)      u2 = (r1 & 0x7fffff) / 2^23   (phi)
+// Both are exactly representable in fp32 and fp64, so the device and the
+// oracle's Philox mode see the same numbers.  The widths are chosen so that the
+// diffuse bounce can build its angles with bit operations instead of an
+// int->float conversion and a multiply (scatter_diffuse_bits).
+constexpr uint32_t U1_MASK = 0x1fffffu, U2_MASK = 0x7fffffu;
+__device__ __forceinline__ float u_theta(uint32_t r0) { return (float)(r0 & U1_MASK) * (1.0f / 2097152.0f); }
+__device__ __forceinline__ float u_phi(uint32_t r1)   { return (float)(r1 & U2_MASK) * (1.0f / 8388608.0f); }
 
 // sin/cos of an angle given in REVOLUTIONS (v_sin_f32 / v_cos_f32 take the
 // argument pre-divided by 2*pi; |x| <= 256).
@@ -156,9 +159,16 @@ __device__ __forceinline__ f3 scatter_diffuse(float4 m1, float4 m2, float m22, f
 }
 
 // The trace kernel's form: the two Philox words go straight to angles.
+//   theta: 0x3f800000 | (r0 & 0x1fffff) is the float 1 + u1/4, and v_sin/v_cos are
+//          periodic in whole revolutions, so that IS the angle 90 deg * u1;
+//   phi:   0x3f800000 | (r1 & 0x7fffff) is f = 1 + u2, and fma(f, P, -P) rounds
+//          P*u2 once, bit for bit the product PHI_REV * u2.
+// One v_and_or_b32 (+ one fma) per angle instead of shift, convert, multiply.
 __device__ __forceinline__ f3 scatter_diffuse_bits(float4 m1, float4 m2, float m22, uint32_t r0, uint32_t r1)
 {
-    const f3 l = local_dir(u24_scaled(r0, THETA_DIFFUSE_REV), u24_scaled(r1, PHI_REV));
+    const float theta_rev = __uint_as_float((r0 & U1_MASK) | 0x3f800000u);
+    const float f = __uint_as_float((r1 & U2_MASK) | 0x3f800000u);
+    const f3 l = local_dir(theta_rev, fmaf(f, PHI_REV, -PHI_REV));
     return mk3(fmaf(m1.z, l.z, fmaf(m1.y, l.y, m1.x * l.x)),
                fmaf(m2.y, l.z, fmaf(m2.x, l.y, m1.w * l.x)),
                fmaf(m22,  l.z, fmaf(m2.w, l.y, m2.z * l.x)));

@@ -259,7 +259,7 @@ __global__ __launch_bounds__(NS == -1 ? TILED_BLOCK : TRACE_BLOCK) void trace_ke
         if constexpr (SPEC) {
             if (e < 0.f) {                                 // _reflective (src/Lib.hs:110)
                 const float4 m3 = mat(idx, 3);
-                return scatter_specular(din, mk3(m3.y, m3.z, m3.w), u24(r0), u24(r1), NOISE_REV);
+                return scatter_specular(din, mk3(m3.y, m3.z, m3.w), u_theta(r0), u_phi(r1), NOISE_REV);
             }
         }
         float4 m1, m2; float m22;
@@ -447,7 +447,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_steal_kernel(TraceArgs a, S
         if constexpr (SPEC) {
             if (e < 0.f) {                                 // _reflective (src/Lib.hs:110)
                 const float4 m3 = mat(idx, 3);
-                return scatter_specular(din, mk3(m3.y, m3.z, m3.w), u24(r0), u24(r1), NOISE_REV);
+                return scatter_specular(din, mk3(m3.y, m3.z, m3.w), u_theta(r0), u_phi(r1), NOISE_REV);
             }
         }
         return scatter_diffuse_bits(mat(idx, 1), mat(idx, 2), mat(idx, 3).x, r0, r1);   // src/Lib.hs:111
@@ -710,7 +710,7 @@ __global__ __launch_bounds__(STATIC_BLOCK) void trace_static_kernel(TraceArgs a,
         if constexpr (SPEC) {
             if (e < -1.5f) {                               // _reflective (src/Lib.hs:110)
                 const float4 m3 = matp(idxp, 3);
-                return scatter_specular(din, mk3(m3.y, m3.z, m3.w), u24(r0), u24(r1), NOISE_REV);
+                return scatter_specular(din, mk3(m3.y, m3.z, m3.w), u_theta(r0), u_phi(r1), NOISE_REV);
             }
         }
         return scatter_diffuse_bits(matp(idxp, 1), matp(idxp, 2), matp(idxp, 3).x, r0, r1);   // src/Lib.hs:111
