@@ -99,8 +99,8 @@ __device__ __forceinline__ void philox2x32_10_pre_v(uint32_t hi0, uint32_t lo0, 
     for (int r = 1; r < 10; ++r) {
         // one v_mad_u64_u32 per round, spelled out: left to itself hipcc widens
         // the multiplier to 64 bits inside the work-sharing loop and emits two
-        uint64_t prod;
-        asm("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(prod) : "v"(c0), "v"(p.m) : "vcc");
+        uint64_t prod, carry;                          // the carry-out goes to a scratch SGPR pair, not vcc
+        asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(prod), "=s"(carry) : "v"(c0), "v"(p.m));
         c0 = __builtin_amdgcn_bitop3_b32((uint32_t)(prod >> 32), p.k[r], c1, 0x96);
         c1 = (uint32_t)prod;
     }
