@@ -37,7 +37,7 @@ if stats:
             calls = int(row["Calls"])
 lines.append("")
 lines.append("# derived")
-SEGS = 6551447147
+SEGS = 6551632325      # segments of one 1080p / 1024-spp / depth-8 frame of the default scene, seed 0 (pt_segments)
 if avg_ms:
     lines.append(f"kernel-trace average duration: {avg_ms:.3f} ms over {calls} calls")
     lines.append(f"algorithmic rate: 97 flop x {SEGS} segments / {avg_ms:.3f} ms = {97 * SEGS / avg_ms / 1e9:.2f} TFLOP/s = "
