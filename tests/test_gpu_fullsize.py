@@ -109,3 +109,40 @@ def test_rgb8_of_full_canvas(pa):
     assert np.array_equal(ref_mode, O.repa3_to_image(p, s.astype(np.float64)))
     want = O.repa3_to_image(p, np.clip(s.astype(np.float64) * (1.0 / spp), 0, 1))
     assert np.array_equal(mean_mode, want)
+
+
+# --- BASELINE.json configs[3] / configs[4]: the synthetic 1,000- and 10,000-object scenes --------
+# Disk variant (the reference has no sphere Form, so only disks have an oracle).
+# configs[3] runs at its full size (3840x2160, 512 spp, depth 8: ~1e13 ray-object tests, seconds on
+# one MI355X).  configs[4] at its full 4096 spp / depth 16 is ~1.5e15 brute-force tests (a quarter of
+# an hour per GPU), so it runs at its full image size, object count and depth with 32 spp.
+
+def _spot_check_scene(pa, H, W, objs, spp, bounces, cam, count, seed):
+    rng = np.random.default_rng(seed)
+    px = np.unique(np.concatenate([rng.integers(0, H * W, count),
+                                   [0, W - 1, (H - 1) * W, H * W - 1, 63, 64, 255, 256, H * W - 65]])).astype(np.int32)
+    with pa.Renderer(pa.Params(H, W, cam, spp, bounces), objs, seed=1) as r:
+        r.trace(spp)
+        dev = r.read_sum().reshape(-1, 3)
+        segs = r.segments
+    ora, _ = O.trace_pixels(O.params(H, W, cam, bounces, O.PHILOX, 1), O.scene_from(objs), px, spp)
+    d = dev[px]
+    rel = np.abs(d - ora) / np.maximum(np.abs(ora), 1e-9)
+    close = ((rel <= 1e-3) | (np.abs(d - ora) <= 1e-4)).all(axis=1)
+    # specular chains amplify rounding differences more than diffuse ones (test_pathwise_parity_random_disks)
+    assert close.mean() >= 0.97, close.mean()
+    assert np.all(np.isfinite(dev)) and dev.min() >= 0.0
+    assert np.abs(d.mean(0) - ora.mean(0)).max() <= 0.02 * max(ora.mean(), 1e-3)
+    assert H * W <= segs <= H * W * (1 + spp * (bounces - 1))
+    return segs
+
+
+def test_config4_thousand_disks_full_size(pa):
+    objs = pa.random_disk_scene(1000, 1)
+    segs = _spot_check_scene(pa, 3840, 2160, objs, 512, 8, 500.0, 160, 44)
+    assert segs > 3840 * 2160 * 512                      # most primary rays hit something and bounce on
+
+
+def test_config5_ten_thousand_disks_full_image_reduced_spp(pa):
+    objs = pa.random_disk_scene(10000, 2)
+    _spot_check_scene(pa, 3840, 2160, objs, 32, 16, 500.0, 60, 45)
