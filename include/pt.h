@@ -89,6 +89,12 @@ typedef struct {
  * default idle lanes help other pixels of their wave and the two differ by
  * fp32 rounding of the per-pixel sum. */
 #define PT_FLAG_NO_STEAL 4
+/* Scenes of more than 8 objects: test every object against every ray, as
+ * closestObjectTo does (src/Lib.hs:81-98), instead of pruning the finite forms
+ * with the bounding-volume hierarchy built at pt_scene_upload.  The two find
+ * the same object (same arithmetic per candidate, ties to the lower index);
+ * this flag is the A/B and parity switch. */
+#define PT_FLAG_NO_BVH 8
 
 typedef struct pt_ctx pt_ctx;
 

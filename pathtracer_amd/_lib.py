@@ -17,6 +17,7 @@ PT_RGB8_REFERENCE, PT_RGB8_MEAN_CLAMP, PT_RGB8_MEAN_GAMMA = 0, 1, 2
 PT_FLAG_NO_PRIMARY_REUSE = 1
 PT_FLAG_LDS_TILES = 2
 PT_FLAG_NO_STEAL = 4
+PT_FLAG_NO_BVH = 8
 
 
 class pt_object(C.Structure):

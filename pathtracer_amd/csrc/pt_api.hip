@@ -5,6 +5,7 @@
 // File:line citations are relative to the reference repository root.
 #include "../../include/pt.h"
 #include "pt_internal.hpp"
+#include "pt_bvh.hpp"
 
 #include <cmath>
 #include <cstdio>
@@ -25,6 +26,10 @@ struct pt_ctx {
     bool canvas_stale = false;                   // pt_reset defers the zeroing to the next pt_trace / read
     float4 *d_geom = nullptr, *d_mat = nullptr;
     double *d_prim = nullptr;
+    float4 *d_bvh_nodes = nullptr;               // spatial index over the finite forms (pt_bvh.hpp), or null
+    int32_t *d_bvh_prims = nullptr;
+    float4 *d_bvh_geom = nullptr;
+    int n_nodes = 0, n_unbounded = 0;
     uint8_t *d_rgb = nullptr;
     int n_obj = 0;
     bool has_specular = false;
@@ -227,6 +232,9 @@ void pt_destroy(pt_ctx *c)
     if (c->d_geom) (void)hipFree(c->d_geom);
     if (c->d_mat) (void)hipFree(c->d_mat);
     if (c->d_prim) (void)hipFree(c->d_prim);
+    if (c->d_bvh_nodes) (void)hipFree(c->d_bvh_nodes);
+    if (c->d_bvh_prims) (void)hipFree(c->d_bvh_prims);
+    if (c->d_bvh_geom) (void)hipFree(c->d_bvh_geom);
     if (c->d_rgb) (void)hipFree(c->d_rgb);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -263,6 +271,10 @@ int pt_scene_upload(pt_ctx *c, const pt_object *objs, int32_t n)
     if (c->d_geom) { (void)hipFree(c->d_geom); c->d_geom = nullptr; }
     if (c->d_mat) { (void)hipFree(c->d_mat); c->d_mat = nullptr; }
     if (c->d_prim) { (void)hipFree(c->d_prim); c->d_prim = nullptr; }
+    if (c->d_bvh_nodes) { (void)hipFree(c->d_bvh_nodes); c->d_bvh_nodes = nullptr; }
+    if (c->d_bvh_prims) { (void)hipFree(c->d_bvh_prims); c->d_bvh_prims = nullptr; }
+    if (c->d_bvh_geom) { (void)hipFree(c->d_bvh_geom); c->d_bvh_geom = nullptr; }
+    c->n_nodes = c->n_unbounded = 0;
     c->n_obj = 0;
     PT_HIP(c, hipMalloc((void **)&c->d_geom, geom.size() * sizeof(float4)));
     PT_HIP(c, hipMalloc((void **)&c->d_mat, mat.size() * sizeof(float4)));
@@ -273,7 +285,55 @@ int pt_scene_upload(pt_ctx *c, const pt_object *objs, int32_t n)
     c->h_geom = geom;
     c->n_obj = n;
     c->has_specular = spec;
+
+    // Spatial index over the finite forms, for scenes beyond the by-value list.
+    if (n > MAX_STATIC_OBJECTS && !(c->p.flags & PT_FLAG_NO_BVH)) {
+        std::vector<BvhBox> boxes((size_t)n);
+        std::vector<int32_t> finite;
+        Bvh bvh;
+        double extent = 0.0;
+        for (int k = 0; k < n; ++k) {
+            if (objs[k].kind != PT_DISK) { bvh.prims.push_back(k); continue; }
+            const double *pr = &prim[(size_t)k * PRIM_DOUBLES];
+            const double r = objs[k].radius > 0.0 ? objs[k].radius : 0.0;      // r <= 0 or NaN: never hit
+            boxes[(size_t)k] = disk_bounds(pr, pr + 6, r);
+            for (int a = 0; a < 3; ++a)
+                extent = std::max(extent, std::max(std::fabs(boxes[(size_t)k].lo[a]), std::fabs(boxes[(size_t)k].hi[a])));
+            finite.push_back(k);
+        }
+        bvh.n_unbounded = (int32_t)bvh.prims.size();
+        if ((int)finite.size() >= BVH_MIN_FINITE && std::isfinite(extent)) {
+            // the device's slab test and ray arithmetic are fp32: a few ulp of the largest
+            // coordinate (1.2e-7 * extent each); the pad is ~100 times that
+            BvhBuilder(boxes, finite, 2e-5 * extent + 1e-30).build(bvh, bvh.n_unbounded);
+            PT_HIP(c, hipMalloc((void **)&c->d_bvh_nodes, bvh.nodes.size() * sizeof(BvhNode)));
+            PT_HIP(c, hipMalloc((void **)&c->d_bvh_prims, bvh.prims.size() * sizeof(int32_t)));
+            PT_HIP(c, hipMemcpy(c->d_bvh_nodes, bvh.nodes.data(), bvh.nodes.size() * sizeof(BvhNode), hipMemcpyHostToDevice));
+            PT_HIP(c, hipMemcpy(c->d_bvh_prims, bvh.prims.data(), bvh.prims.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+            // the geometry again in leaf order, object index in [2].w, + BVH_LEAF_MAX never-hit records
+            std::vector<float4> lg((bvh.prims.size() + BVH_LEAF_MAX) * 3);
+            for (size_t sl = 0; sl < bvh.prims.size() + BVH_LEAF_MAX; ++sl) {
+                const int k = sl < bvh.prims.size() ? bvh.prims[sl] : n;        // n: the first pad record of `geom`
+                for (int f = 0; f < 3; ++f) lg[sl * 3 + f] = geom[(size_t)k * 3 + f];
+                lg[sl * 3 + 2].w = __builtin_bit_cast(float, (int32_t)(sl < bvh.prims.size() ? k : 0x7fffffff));
+            }
+            PT_HIP(c, hipMalloc((void **)&c->d_bvh_geom, lg.size() * sizeof(float4)));
+            PT_HIP(c, hipMemcpy(c->d_bvh_geom, lg.data(), lg.size() * sizeof(float4), hipMemcpyHostToDevice));
+            c->n_nodes = (int)bvh.nodes.size();
+            c->n_unbounded = bvh.n_unbounded;
+        }
+    }
     return PT_OK;
+}
+
+// the fields of TraceArgs that describe the scene
+static void scene_args(const pt_ctx *c, TraceArgs &a)
+{
+    a.geom = c->d_geom; a.mat = c->d_mat; a.prim = c->d_prim;
+    a.camera_depth = c->p.camera_depth;
+    a.n_obj = c->n_obj; a.height = c->p.height; a.width = c->p.width;
+    a.bvh_nodes = c->d_bvh_nodes; a.bvh_prims = c->d_bvh_prims; a.bvh_geom = c->d_bvh_geom;
+    a.n_nodes = c->n_nodes; a.n_unbounded = c->n_unbounded;
 }
 
 int pt_trace(pt_ctx *c, int32_t iters)
@@ -295,9 +355,7 @@ int pt_trace(pt_ctx *c, int32_t iters)
         TraceArgs a{};
         a.canvas = c->d_canvas; a.segments = c->d_segments + (size_t)c->seg_slot * SEG_EPOCH;
         a.fresh = c->canvas_stale ? 1 : 0;           // the canvas is logically zero: do not read it
-        a.geom = c->d_geom; a.mat = c->d_mat; a.prim = c->d_prim;
-        a.camera_depth = c->p.camera_depth;
-        a.n_obj = c->n_obj; a.height = c->p.height; a.width = c->p.width;
+        scene_args(c, a);
         a.max_bounces = c->p.max_bounces; a.seed = c->p.seed;
         a.sample_begin = (uint32_t)(c->p.sample_offset + c->samples_done * c->p.sample_stride);
         a.sample_stride = (uint32_t)c->p.sample_stride;
@@ -415,8 +473,9 @@ int pt_primary_hits(pt_ctx *c, int32_t *idx, double *t, double *normal)
         if (idx && (e = hipMalloc((void **)&d_idx, n * sizeof(int32_t))) != hipSuccess) break;
         if (t && (e = hipMalloc((void **)&d_t, n * sizeof(double))) != hipSuccess) break;
         if (normal && (e = hipMalloc((void **)&d_n, n * 3 * sizeof(double))) != hipSuccess) break;
-        if ((e = launch_primary(c->d_prim, c->n_obj, c->p.height, c->p.width, c->p.camera_depth, d_idx, d_t,
-                                d_n, c->stream)) != hipSuccess) break;
+        TraceArgs a{};
+        scene_args(c, a);
+        if ((e = launch_primary(a, d_idx, d_t, d_n, c->stream)) != hipSuccess) break;
         if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) break;
         if (idx && (e = hipMemcpy(idx, d_idx, n * sizeof(int32_t), hipMemcpyDeviceToHost)) != hipSuccess) break;
         if (t && (e = hipMemcpy(t, d_t, n * sizeof(double), hipMemcpyDeviceToHost)) != hipSuccess) break;

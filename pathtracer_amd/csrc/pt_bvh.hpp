@@ -1,0 +1,196 @@
+// pt_bvh.hpp -- host-side builder of the spatial index over the FINITE forms of
+// a scene (Disk, src/Object.hs:51-54); InfinitePlane (:55-56) has no bounds and
+// stays on a short list that every ray tests.
+//
+// The reference's closestObjectTo is a linear scan over all objects
+// (src/Lib.hs:81-98).  The index only prunes candidates: every object whose
+// (inflated) bounding box the ray can reach before the best hit so far is tested
+// with the SAME arithmetic as the linear scan, and ties are broken by object
+// index as Data.Vector.minimumBy does, so the winner is the linear scan's winner.
+//
+// Layout: binary BVH in depth-first order, one 32-byte node per box.  A lane
+// walks it near child first (by the sign of the ray direction along the node's
+// split axis) with a short per-lane stack of far children in LDS; every node is
+// one 32-byte gather from L2.  Depth is bounded (BVH_MAX_DEPTH) so the stack
+// cannot overflow whatever the scene.
+#pragma once
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <limits>
+#include <vector>
+
+namespace pt {
+
+// 32 bytes: lo.xyz, skip | hi.xyz, leaf
+//   skip: index of the first node after this subtree (depth-first order)
+//   leaf: >= 0: first_prim << 3 | (count - 1)
+//         <  0: inner node, -(code + 1) with code = right_child << 2 | split_axis; left child = this + 1
+struct BvhNode {
+    float lo[3]; int32_t skip;
+    float hi[3]; int32_t leaf;
+};
+static_assert(sizeof(BvhNode) == 32, "two float4 per node");
+
+constexpr int BVH_LEAF_MAX = 4;
+constexpr int BVH_SAH_DEPTH = 14;       // surface-area splits down to here, balanced median splits below:
+constexpr int BVH_MAX_DEPTH = 30;       //   14 + ceil(log2(65536 / 4)) = 28 levels at most
+constexpr int BVH_STACK = 32;           // per-lane stack entries on the device (> BVH_MAX_DEPTH)
+constexpr int BVH_MIN_FINITE = 16;      // below this the linear scan is used
+
+struct Bvh {
+    std::vector<BvhNode> nodes;
+    std::vector<int32_t> prims;          // [unbounded objects..., finite objects in leaf order...]
+    int32_t n_unbounded = 0;
+    bool usable() const { return !nodes.empty(); }
+};
+
+struct BvhBox { double lo[3], hi[3]; };
+
+// centre, unit normal, radius of a Disk -> axis-aligned bounds
+inline BvhBox disk_bounds(const double c[3], const double nhat[3], double r)
+{
+    BvhBox b;
+    for (int a = 0; a < 3; ++a) {
+        const double h = r * std::sqrt(std::max(0.0, 1.0 - nhat[a] * nhat[a]));
+        b.lo[a] = c[a] - h; b.hi[a] = c[a] + h;
+    }
+    return b;
+}
+
+class BvhBuilder {
+public:
+    BvhBuilder(const std::vector<BvhBox> &boxes, const std::vector<int32_t> &ids, double pad)
+        : boxes_(boxes), pad_(pad), order_(ids) {}
+
+    void build(Bvh &out, int32_t prim_base)
+    {
+        prim_base_ = prim_base;
+        out_ = &out;
+        emit(0, (int)order_.size(), 0);
+        // skip links: a node's subtree occupies [i, end_i); its skip is end_i
+        for (size_t i = 0; i < out.nodes.size(); ++i) out.nodes[i].skip = end_[i];
+        for (int32_t id : order_) out.prims.push_back(id);
+    }
+
+private:
+    const std::vector<BvhBox> &boxes_;
+    double pad_;
+    std::vector<int32_t> order_;          // positions into boxes_ == object ids are looked up via ids
+    std::vector<int32_t> end_;
+    Bvh *out_ = nullptr;
+    int32_t prim_base_ = 0;
+
+    BvhBox bounds(int b, int e) const
+    {
+        BvhBox r;
+        for (int a = 0; a < 3; ++a) { r.lo[a] = std::numeric_limits<double>::infinity(); r.hi[a] = -r.lo[a]; }
+        for (int i = b; i < e; ++i)
+            for (int a = 0; a < 3; ++a) {
+                r.lo[a] = std::min(r.lo[a], boxes_[order_[i]].lo[a]);
+                r.hi[a] = std::max(r.hi[a], boxes_[order_[i]].hi[a]);
+            }
+        return r;
+    }
+    static double area(const BvhBox &b)
+    {
+        const double x = b.hi[0] - b.lo[0], y = b.hi[1] - b.lo[1], z = b.hi[2] - b.lo[2];
+        return 2.0 * (x * y + y * z + z * x);
+    }
+    double centroid(int i, int a) const { return 0.5 * (boxes_[order_[i]].lo[a] + boxes_[order_[i]].hi[a]); }
+
+    // emits the subtree over order_[b, e) in depth-first order
+    void emit(int b, int e, int depth)
+    {
+        const int me = (int)out_->nodes.size();
+        out_->nodes.push_back(BvhNode{});
+        end_.push_back(0);
+        const BvhBox bb = bounds(b, e);
+        BvhNode n;
+        for (int a = 0; a < 3; ++a) {
+            // round outward to fp32, then pad: the device's slab test is plain fp32
+            n.lo[a] = std::nextafter((float)(bb.lo[a] - pad_), -std::numeric_limits<float>::infinity());
+            n.hi[a] = std::nextafter((float)(bb.hi[a] + pad_), std::numeric_limits<float>::infinity());
+        }
+        n.skip = 0;
+        const int cnt = e - b;
+        if (cnt <= BVH_LEAF_MAX) {
+            n.leaf = ((prim_base_ + b) << 3) | (cnt - 1);
+            out_->nodes[me] = n;
+            end_[me] = (int32_t)out_->nodes.size();
+            return;
+        }
+        n.leaf = -1;
+        out_->nodes[me] = n;
+        // binned SAH over the centroids of the widest axes; median split as the fallback
+        int best_axis = -1, best_split = -1;
+        double best_cost = std::numeric_limits<double>::infinity();
+        constexpr int BINS = 16;
+        for (int a = 0; a < 3 && depth < BVH_SAH_DEPTH; ++a) {
+            double cmin = std::numeric_limits<double>::infinity(), cmax = -cmin;
+            for (int i = b; i < e; ++i) { cmin = std::min(cmin, centroid(i, a)); cmax = std::max(cmax, centroid(i, a)); }
+            if (!(cmax > cmin)) continue;
+            BvhBox bin_box[BINS]; int bin_cnt[BINS] = {0};
+            for (auto &q : bin_box) for (int x = 0; x < 3; ++x) { q.lo[x] = std::numeric_limits<double>::infinity(); q.hi[x] = -q.lo[x]; }
+            const double scale = BINS / (cmax - cmin);
+            for (int i = b; i < e; ++i) {
+                int k = std::min(BINS - 1, (int)((centroid(i, a) - cmin) * scale));
+                bin_cnt[k]++;
+                for (int x = 0; x < 3; ++x) {
+                    bin_box[k].lo[x] = std::min(bin_box[k].lo[x], boxes_[order_[i]].lo[x]);
+                    bin_box[k].hi[x] = std::max(bin_box[k].hi[x], boxes_[order_[i]].hi[x]);
+                }
+            }
+            double right_area[BINS]; int right_cnt[BINS];
+            BvhBox acc = bin_box[BINS - 1]; int c = 0;
+            for (int k = BINS - 1; k >= 1; --k) {
+                if (k < BINS - 1)
+                    for (int x = 0; x < 3; ++x) { acc.lo[x] = std::min(acc.lo[x], bin_box[k].lo[x]); acc.hi[x] = std::max(acc.hi[x], bin_box[k].hi[x]); }
+                c += bin_cnt[k];
+                right_area[k] = c ? area(acc) : 0.0; right_cnt[k] = c;
+            }
+            acc = bin_box[0]; c = 0;
+            for (int k = 0; k < BINS - 1; ++k) {
+                if (k > 0)
+                    for (int x = 0; x < 3; ++x) { acc.lo[x] = std::min(acc.lo[x], bin_box[k].lo[x]); acc.hi[x] = std::max(acc.hi[x], bin_box[k].hi[x]); }
+                c += bin_cnt[k];
+                if (c == 0 || right_cnt[k + 1] == 0) continue;
+                const double cost = area(acc) * c + right_area[k + 1] * right_cnt[k + 1];
+                if (cost < best_cost) { best_cost = cost; best_axis = a; best_split = k; }
+            }
+            if (best_axis == a) { split_min_ = cmin; split_scale_ = scale; }
+        }
+        int mid, axis = best_axis;
+        if (best_axis >= 0) {
+            const int a = best_axis; const double cmin = split_min_, scale = split_scale_; const int ks = best_split;
+            auto it = std::partition(order_.begin() + b, order_.begin() + e, [&](int32_t id) {
+                const double cc = 0.5 * (boxes_[id].lo[a] + boxes_[id].hi[a]);
+                return std::min(BINS - 1, (int)((cc - cmin) * scale)) <= ks;
+            });
+            mid = (int)(it - order_.begin());
+        } else {
+            mid = b;
+        }
+        if (mid <= b || mid >= e) {                    // degenerate (coincident centroids): median by the widest axis
+            int a = 0; double w = -1;
+            for (int x = 0; x < 3; ++x) if (bb.hi[x] - bb.lo[x] > w) { w = bb.hi[x] - bb.lo[x]; a = x; }
+            mid = (b + e) / 2;
+            axis = a;
+            std::nth_element(order_.begin() + b, order_.begin() + mid, order_.begin() + e, [&](int32_t p, int32_t q) {
+                return boxes_[p].lo[a] + boxes_[p].hi[a] < boxes_[q].lo[a] + boxes_[q].hi[a];
+            });
+        }
+        emit(b, mid, depth + 1);                       // the low side of `axis` first
+        const int32_t right = (int32_t)out_->nodes.size();
+        emit(mid, e, depth + 1);
+        out_->nodes[me].leaf = -(((right << 2) | axis) + 1);
+        end_[me] = (int32_t)out_->nodes.size();
+        if (depth + 1 > max_depth) max_depth = depth + 1;
+    }
+    double split_min_ = 0, split_scale_ = 0;
+public:
+    int max_depth = 0;
+};
+
+} // namespace pt

@@ -290,4 +290,106 @@ __device__ inline PrimaryHit primary_hit_f64(const double *__restrict__ prim, in
     return h;
 }
 
+// ---- the same search through the spatial index ------------------------------
+// Binary BVH over the finite forms (pt_bvh.hpp).  Pruning only: every candidate
+// runs the arithmetic of the linear scan, and an equal t keeps the lower object
+// index, so the result is the scan's.  The slab test is fp32 on boxes the host
+// rounded outward and padded.
+__device__ __forceinline__ bool slab_hit(float4 n0, float4 n1, float ox, float oy, float oz,
+                                         float ix, float iy, float iz, float t_best)
+{
+    const float ax = (n0.x - ox) * ix, bx = (n1.x - ox) * ix;
+    const float ay = (n0.y - oy) * iy, by = (n1.y - oy) * iy;
+    const float az = (n0.z - oz) * iz, bz = (n1.z - oz) * iz;
+    const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
+    const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), t_best));
+    return tn <= tf;
+}
+
+constexpr int BVH_STACK_ENTRIES = 32;
+constexpr int BVH_LEAF_SLOTS = 4;         // = BVH_LEAF_MAX of pt_bvh.hpp    // = BVH_STACK of pt_bvh.hpp (tree depth <= 30)
+
+// Near-child-first walk.  `stack` is this lane's column of an LDS array laid out
+// [entry][lane] (stride = lanes per workgroup): conflict-free, no scratch memory.
+// `t_best()` is read at every node, so subtrees pushed earlier are pruned against
+// the best hit found since; `leaf(first, cnt)` tests the objects in slots
+// [first, first + cnt) of the leaf-ordered lists.
+template <typename LeafFn, typename BestFn>
+__device__ __forceinline__ void bvh_walk(const float4 *__restrict__ nodes,
+                                         float ox, float oy, float oz, float dx, float dy, float dz,
+                                         int *stack, int stride, LeafFn &&leaf, BestFn &&t_best)
+{
+    const float ix = __builtin_amdgcn_rcpf(dx), iy = __builtin_amdgcn_rcpf(dy), iz = __builtin_amdgcn_rcpf(dz);
+    const uint32_t neg = (dx < 0.f ? 1u : 0u) | (dy < 0.f ? 2u : 0u) | (dz < 0.f ? 4u : 0u);
+    // "while-while" (Aila & Laine, HPG'09): every lane first walks inner nodes until
+    // it holds a leaf or runs out of nodes; only then do the lanes test their
+    // leaves together.  A wave pays for the (long) leaf block once per round
+    // instead of on every step in which any one of its 64 lanes is at a leaf.
+    int sp = 0, n = 0;
+    auto pop = [&]() -> int {
+        if (sp == 0) return -1;
+        sp -= 1;
+        return stack[sp * stride];
+    };
+    for (;;) {
+        int code = -1;
+        while (n >= 0) {
+            const float4 n0 = nodes[2 * n], n1 = nodes[2 * n + 1];
+            if (!slab_hit(n0, n1, ox, oy, oz, ix, iy, iz, t_best())) { n = pop(); continue; }
+            const int c = __float_as_int(n1.w);
+            if (c >= 0) { code = c; break; }
+            const int cc = -(c + 1), right = cc >> 2, left = n + 1;
+            const bool right_first = (neg >> (cc & 3)) & 1u;
+            stack[sp * stride] = right_first ? left : right;
+            sp += 1;
+            n = right_first ? right : left;
+        }
+        if (code < 0) break;
+        leaf(code >> 3, (code & 7) + 1);                      // first slot, count (<= 4)
+        n = pop();
+    }
+}
+
+__device__ inline PrimaryHit primary_hit_f64_bvh(const double *__restrict__ prim, const float4 *__restrict__ nodes,
+                                                 const int32_t *__restrict__ prims, int n_unbounded,
+                                                 int H, int W, double camera_depth, int i, int j, int *stack, int stride)
+{
+#pragma clang fp contract(off)
+    PrimaryHit h;
+    const double ip = (double)H / 2.0 - (double)i;
+    const double jp = (double)j - (double)W / 2.0;
+    const double nrm = sqrt(ip * ip + jp * jp + camera_depth * camera_depth);
+    const double floor_ = 1e-6;
+    const double norm = (floor_ <= nrm) ? nrm : floor_;
+    h.dx = ip / norm; h.dy = jp / norm; h.dz = camera_depth / norm;
+    h.idx = -1; h.t = 0.0;
+    auto test = [&](int k) {
+        const double *p = prim + (size_t)k * PRIM_DOUBLES;
+        double num = 0.0;
+        num = num + (p[0] - 0.0) * p[3];
+        num = num + (p[1] - 0.0) * p[4];
+        num = num + (p[2] - 0.0) * p[5];
+        double den = 0.0;
+        den = den + h.dx * p[6];
+        den = den + h.dy * p[7];
+        den = den + h.dz * p[8];
+        const double t = num / den;
+        bool ok = (0.0 < t) && (t < (double)__builtin_inff());
+        if (ok && p[10] != 0.0) {                             // Disk
+            const double px = 0.0 + t * h.dx - p[0];
+            const double py = 0.0 + t * h.dy - p[1];
+            const double pz = 0.0 + t * h.dz - p[2];
+            ok = sqrt(px * px + py * py + pz * pz) < p[9];
+        }
+        // minimumBy keeps the earlier element on equal t (src/Lib.hs:84)
+        if (ok && (h.idx < 0 || t < h.t || (t == h.t && k < h.idx))) { h.idx = k; h.t = t; }
+    };
+    for (int u = 0; u < n_unbounded; ++u) test(prims[u]);
+    // the fp64 t is compared in fp32 by the slab test: widen it by one part in 2^20
+    bvh_walk(nodes, 0.f, 0.f, 0.f, (float)h.dx, (float)h.dy, (float)h.dz, stack, stride,
+             [&](int first, int cnt) { for (int q = 0; q < cnt; ++q) test(prims[first + q]); },
+             [&]() { return h.idx < 0 ? __builtin_inff() : (float)h.t * 1.000001f; });
+    return h;
+}
+
 } // namespace pt

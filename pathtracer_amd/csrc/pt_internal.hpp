@@ -38,13 +38,18 @@ struct TraceArgs {
     int      n_samples;                // samples per pixel in this launch
     int      fresh;                    // 1: the canvas is logically zero, start the sums at 0 without reading it
     int      tile_objs;                // objects per LDS tile (tiled kernel; set by the launcher)
+    // spatial index over the finite forms (pt_bvh.hpp); n_nodes == 0: none, linear scan
+    const float4  *bvh_nodes;          // 2 float4 per node: (lo.xyz, skip) (hi.xyz, leaf)
+    const int32_t *bvh_prims;          // [unbounded objects..., finite objects in leaf order...]
+    const float4  *bvh_geom;           // geometry records in bvh_prims order (3 float4 each, object index in [2].w), padded
+    int      n_nodes;
+    int      n_unbounded;
 };
 
 // Launchers (pt_kernels.hip).  All return the hipError_t of the launch.
 hipError_t launch_trace(const TraceArgs &a, const float4 *geom_host, bool reuse_primary,
                         bool has_specular, bool lds_tiles, bool steal, hipStream_t s);
-hipError_t launch_primary(const double *prim, int n_obj, int H, int W, double camera_depth,
-                          int32_t *idx, double *t, double *normal, hipStream_t s);
+hipError_t launch_primary(const TraceArgs &a, int32_t *idx, double *t, double *normal, hipStream_t s);
 hipError_t launch_rgb8(const float *canvas, uint8_t *rgb, int H, int W, int mode,
                        double inv_samples, hipStream_t s);
 hipError_t launch_dev_diffuse(int n, const float4 *mat1, const float *u, float *out, hipStream_t s);

@@ -101,15 +101,67 @@ __device__ __forceinline__ void key_result(int &best, uint32_t best_key, float &
     best_t = __uint_as_float(best_key + 1u);
 }
 
+// the per-pixel fp64 primary segment, through the spatial index when the scene has one
+__device__ __forceinline__ PrimaryHit primary_hit(const TraceArgs &a, int pi, int pj, int *stack = nullptr, int stride = 0)
+{
+    if (a.n_nodes > 0 && stack)
+        return primary_hit_f64_bvh(a.prim, a.bvh_nodes, a.bvh_prims, a.n_unbounded, a.height, a.width,
+                                   a.camera_depth, pi, pj, stack, stride);
+    return primary_hit_f64(a.prim, a.n_obj, a.height, a.width, a.camera_depth, pi, pj);
+}
+
 // LDS tile of geometry records for the tiled kernel (NS == -1), dynamic size.
 extern __shared__ float4 s_tile[];
 
 template <int NS>
 __device__ __forceinline__ void closest(const TraceArgs &a, const StaticGeom<NS> &sg, f3 o, f3 v,
-                                        int last, int &best, float &best_t)
+                                        int last, int &best, float &best_t, int *stack = nullptr, int stride = 0)
 {
     best = -1; best_t = __builtin_inff();
     uint32_t best_key = KEY_LIMIT;
+    if constexpr (NS == -2) {
+        // Spatial index (pt_bvh.hpp): the unbounded forms first, then a
+        // near-child-first walk of the BVH.  Each lane follows its own chain of
+        // node indices (32-byte gathers from L2, far children on an LDS stack);
+        // candidates run test_object_key's arithmetic, and an equal key keeps the
+        // lower object index, so the winner is the linear scan's.
+        // a.bvh_geom: the geometry records again, in leaf order (slot s of
+        // bvh_prims), with the object index in g2.w -- a leaf's records are
+        // contiguous, so all their loads are issued at once (one L2 round trip
+        // per leaf instead of two dependent ones per object).
+        const float4 *__restrict__ g = a.bvh_geom;
+        float bt = __builtin_inff();
+        auto test = [&](float4 g0, float4 g1, float4 g2, bool on) {
+            const int k = __float_as_int(g2.w);
+            const float onr = fmaf(o.z, g0.z, fmaf(o.y, g0.y, o.x * g0.x));
+            const float den = fmaf(v.z, g1.z, fmaf(v.y, g1.y, v.x * g1.x));
+            const float t = (g0.w - onr) * __builtin_amdgcn_rcpf(den);
+            uint32_t key = __float_as_uint(t) - 1u;
+            key = (k == last || !on) ? KEY_INVALID : key;     // _lastStruck (src/Lib.hs:86-90)
+            const float dx = fmaf(t, v.x, o.x) - g2.x;         // Disk (src/Object.hs:165-171); a plane has r2 = +Inf
+            const float dy = fmaf(t, v.y, o.y) - g2.y;
+            const float dz = fmaf(t, v.z, o.z) - g2.z;
+            key = (fmaf(dz, dz, fmaf(dy, dy, dx * dx)) < g1.w || g1.w == __builtin_inff()) ? key : KEY_INVALID;
+            const bool better = (key < best_key) | ((key == best_key) & (key < KEY_LIMIT) & (k < best));
+            best = better ? k : best;
+            best_key = better ? key : best_key;
+            bt = better ? t : bt;
+        };
+        for (int u = 0; u < a.n_unbounded; ++u) test(g[3 * u], g[3 * u + 1], g[3 * u + 2], true);
+        bvh_walk(a.bvh_nodes, o.x, o.y, o.z, v.x, v.y, v.z, stack, stride,
+                 [&](int first, int cnt) {
+                     float4 r[BVH_LEAF_SLOTS][3];
+#pragma unroll
+                     for (int q = 0; q < BVH_LEAF_SLOTS; ++q) {           // the list is padded: slots past cnt are loadable
+                         r[q][0] = g[3 * (first + q)]; r[q][1] = g[3 * (first + q) + 1]; r[q][2] = g[3 * (first + q) + 2];
+                     }
+#pragma unroll
+                     for (int q = 0; q < BVH_LEAF_SLOTS; ++q) test(r[q][0], r[q][1], r[q][2], q < cnt);
+                 },
+                 [&]() { return bt; });
+        key_result(best, best_key, best_t);
+        return;
+    }
     if constexpr (NS == -1) {
         // Object list staged in LDS per workgroup.  A scene that fits one tile
         // was staged once at kernel start and the waves run free; a larger one
@@ -177,6 +229,8 @@ template <int NS, bool REUSE, bool SPEC>
 __global__ __launch_bounds__(NS == -1 ? TILED_BLOCK : TRACE_BLOCK) void trace_kernel(TraceArgs a, StaticGeom<NS> sg)
 {
     constexpr int BLOCK = NS == -1 ? TILED_BLOCK : TRACE_BLOCK;
+    __shared__ int s_stack[(NS == -2 ? BVH_STACK_ENTRIES : 1) * (NS == -2 ? BLOCK : 1)];   // BVH walk: [entry][lane]
+    int *const stack = NS == -2 ? &s_stack[threadIdx.x] : nullptr;
     bool lockstep = false;
     if constexpr (NS == -1) {
         lockstep = a.n_obj > a.tile_objs;
@@ -224,7 +278,7 @@ __global__ __launch_bounds__(NS == -1 ? TILED_BLOCK : TRACE_BLOCK) void trace_ke
 
     // Primary segment: no jitter, no randomness (src/Lib.hs:41-51), so it is
     // computed once per pixel, in fp64, reference operation order.
-    const PrimaryHit ph = primary_hit_f64(a.prim, a.n_obj, a.height, a.width, a.camera_depth, pi, pj);
+    const PrimaryHit ph = primary_hit(a, pi, pj, stack, BLOCK);
     const f3 d0 = mk3((float)ph.dx, (float)ph.dy, (float)ph.dz);
     const int B = a.max_bounces;
 
@@ -283,7 +337,7 @@ __global__ __launch_bounds__(NS == -1 ? TILED_BLOCK : TRACE_BLOCK) void trace_ke
             if (!alive) break;
         }
         int k; float t;
-        closest<NS>(a, sg, o, d, last, k, t);
+        closest<NS>(a, sg, o, d, last, k, t, stack, BLOCK);
         segs += alive ? 1 : 0;
         const bool hit = k >= 0;
         const float4 m0 = mat(hit ? k : 0, 0);
@@ -352,14 +406,14 @@ __global__ __launch_bounds__(NS == -1 ? TILED_BLOCK : TRACE_BLOCK) void trace_ke
 // sample does not change it; only the fp32 summation order of a pixel's samples
 // can change (PT_FLAG_NO_STEAL keeps the strictly sequential sum).
 template <int NS, bool SPEC>
-__global__ __launch_bounds__(TRACE_BLOCK) void trace_steal_kernel(TraceArgs a, StaticGeom<NS> sg,
+__global__ __launch_bounds__(NS == -2 ? 64 : TRACE_BLOCK) void trace_steal_kernel(TraceArgs a, StaticGeom<NS> sg,
                                                                   const float4 *__restrict__ geom_ro)
 {
     // geom_ro is the object list again, as a noalias read-only parameter: with LDS
     // atomics in the loop hipcc otherwise stops proving the list unclobbered and
     // turns the wave-uniform s_load stream into per-lane vector loads.
     a.geom = geom_ro;
-    static_assert(NS >= 0, "work sharing is built for the SGPR and scalar-stream object lists");
+    static_assert(NS >= 0 || NS == -2, "work sharing is built for the SGPR, scalar-stream and BVH object lists");
     if constexpr (NS > 0) {
         auto fv = [](float &x) { x = __uint_as_float(to_vgpr(__float_as_uint(x))); };
 #pragma unroll
@@ -378,8 +432,10 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_steal_kernel(TraceArgs a, S
 #endif
         }
     }
-    constexpr int BLOCK = TRACE_BLOCK;
+    constexpr int BLOCK = NS == -2 ? 64 : TRACE_BLOCK;      // BVH walks diverge: one wave per workgroup, 8-KB stack
     constexpr int MAT_LDS_STRIDE = 5;
+    __shared__ int s_stack[(NS == -2 ? BVH_STACK_ENTRIES : 1) * (NS == -2 ? BLOCK : 1)];   // BVH walk: [entry][lane]
+    int *const stack = NS == -2 ? &s_stack[threadIdx.x] : nullptr;
     __shared__ float4   s_mat[(NS > 0 ? NS : 1) * MAT_LDS_STRIDE];
     __shared__ uint32_t s_next[BLOCK];          // per pixel: next sample (launch-local index) not started
     __shared__ float4   s_pix[BLOCK * 3];       // per pixel: P0, d0, colour0, idx0, e0
@@ -408,7 +464,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_steal_kernel(TraceArgs a, S
     if (in_canvas && !a.fresh) acc = mk3(a.canvas[3 * (size_t)pc + 0], a.canvas[3 * (size_t)pc + 1], a.canvas[3 * (size_t)pc + 2]);
 
     // primary segment, once per pixel, fp64 (src/Lib.hs:41-51, :81-98)
-    const PrimaryHit ph = primary_hit_f64(a.prim, a.n_obj, a.height, a.width, a.camera_depth, pi, pj);
+    const PrimaryHit ph = primary_hit(a, pi, pj, stack, BLOCK);
     f3 cd0 = mk3((float)ph.dx, (float)ph.dy, (float)ph.dz);
     f3 cP0 = mk3((float)(ph.t * ph.dx), (float)(ph.t * ph.dy), (float)(ph.t * ph.dz));
     f3 ccol = mk3(1.f, 1.f, 1.f);
@@ -457,7 +513,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_steal_kernel(TraceArgs a, S
     // `all_alive` (compile-time): phase 1 only runs while every lane has a path.
     auto trip = [&](auto all_alive, auto &&draw) {
         int k; float t;
-        closest<NS>(a, sg, o, d, last, k, t);
+        closest<NS>(a, sg, o, d, last, k, t, stack, BLOCK);
         const bool live = decltype(all_alive)::value ? true : alive;
 #if PT_EXP & 4
         if (!decltype(all_alive)::value) segs += live ? 1 : 0;      // phase 1 counts its trips wave-uniformly
@@ -678,7 +734,7 @@ __global__ __launch_bounds__(STATIC_BLOCK) void trace_static_kernel(TraceArgs a,
     if (in_canvas && !a.fresh) acc = mk3(a.canvas[3 * (size_t)pc + 0], a.canvas[3 * (size_t)pc + 1], a.canvas[3 * (size_t)pc + 2]);
 
     // primary segment, once per pixel, fp64 (src/Lib.hs:41-51, :81-98)
-    const PrimaryHit ph = primary_hit_f64(a.prim, a.n_obj, a.height, a.width, a.camera_depth, pi, pj);
+    const PrimaryHit ph = primary_hit(a, pi, pj);
     f3 cd0 = mk3((float)ph.dx, (float)ph.dy, (float)ph.dz);
     f3 cP0 = mk3((float)(ph.t * ph.dx), (float)(ph.t * ph.dy), (float)(ph.t * ph.dz));
     f3 ccol = mk3(1.f, 1.f, 1.f);
@@ -857,10 +913,12 @@ static hipError_t launch_trace_ns(TraceArgs a, const float4 *geom_host, bool reu
         }
     }
 #endif
-    if constexpr (NS >= 0) {
+    if constexpr (NS >= 0 || NS == -2) {
         if (steal && reuse) {
-            if (spec) hipLaunchKernelGGL((trace_steal_kernel<NS, true>), grid, block, 0, s, a, sg, a.geom);
-            else      hipLaunchKernelGGL((trace_steal_kernel<NS, false>), grid, block, 0, s, a, sg, a.geom);
+            constexpr int SB = NS == -2 ? 64 : TRACE_BLOCK;
+            const dim3 tgrid((npix + SB - 1) / SB), tblock(SB);
+            if (spec) hipLaunchKernelGGL((trace_steal_kernel<NS, true>), tgrid, tblock, 0, s, a, sg, a.geom);
+            else      hipLaunchKernelGGL((trace_steal_kernel<NS, false>), tgrid, tblock, 0, s, a, sg, a.geom);
             return hipGetLastError();
         }
     }
@@ -880,34 +938,33 @@ hipError_t launch_trace(const TraceArgs &a, const float4 *geom_host, bool reuse,
     if (a.n_obj <= 4) return launch_trace_ns<4>(a, geom_host, reuse, spec, steal, s);
     if (a.n_obj <= MAX_STATIC_OBJECTS) return launch_trace_ns<MAX_STATIC_OBJECTS>(a, geom_host, reuse, spec, steal, s);
     if (lds_tiles) return launch_trace_ns<-1>(a, geom_host, reuse, spec, false, s);
+    if (a.n_nodes > 0) return launch_trace_ns<-2>(a, geom_host, reuse, spec, steal, s);
     return launch_trace_ns<0>(a, geom_host, reuse, spec, steal, s);
 }
 
 // ---------------------------------------------------------------------------
 // primary hits (fp64), parity hook
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void primary_kernel(const double *__restrict__ prim, int n_obj, int H,
-                                                      int W, double camera_depth, int32_t *idx,
-                                                      double *t, double *normal)
+__global__ __launch_bounds__(256) void primary_kernel(TraceArgs a, int32_t *idx, double *t, double *normal)
 {
+    __shared__ int s_stack[BVH_STACK_ENTRIES * 256];
+    const int H = a.height, W = a.width;
     const int pixel = blockIdx.x * 256 + threadIdx.x;
     if (pixel >= H * W) return;
     const int i = pixel / W, j = pixel - i * W;
-    const PrimaryHit h = primary_hit_f64(prim, n_obj, H, W, camera_depth, i, j);
+    const PrimaryHit h = primary_hit(a, i, j, &s_stack[threadIdx.x], 256);
     if (idx) idx[pixel] = h.idx;
     if (t) t[pixel] = h.idx >= 0 ? h.t : 0.0;
     if (normal) {
         for (int c = 0; c < 3; ++c)
-            normal[3 * (size_t)pixel + c] = h.idx >= 0 ? prim[(size_t)h.idx * PRIM_DOUBLES + 3 + c] : 0.0;
+            normal[3 * (size_t)pixel + c] = h.idx >= 0 ? a.prim[(size_t)h.idx * PRIM_DOUBLES + 3 + c] : 0.0;
     }
 }
 
-hipError_t launch_primary(const double *prim, int n_obj, int H, int W, double camera_depth,
-                          int32_t *idx, double *t, double *normal, hipStream_t s)
+hipError_t launch_primary(const TraceArgs &a, int32_t *idx, double *t, double *normal, hipStream_t s)
 {
-    const int npix = H * W;
-    hipLaunchKernelGGL(primary_kernel, dim3((npix + 255) / 256), dim3(256), 0, s, prim, n_obj, H, W,
-                       camera_depth, idx, t, normal);
+    const int npix = a.height * a.width;
+    hipLaunchKernelGGL(primary_kernel, dim3((npix + 255) / 256), dim3(256), 0, s, a, idx, t, normal);
     return hipGetLastError();
 }
 

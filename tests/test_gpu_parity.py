@@ -438,3 +438,48 @@ def test_reset_is_lazy_but_exact(pa):
         assert not a.read_sum_f32().any() and a.segments == 0
         a.reset()
         assert a.read_rgb8().max() == 0
+
+
+@pytest.mark.parametrize("steal_flag", [0, 4])
+@pytest.mark.parametrize("n,seed,bounces", [(17, 21, 6), (40, 7, 6), (300, 8, 5), (1025, 10, 4), (2500, 11, 6)])
+def test_spatial_index_finds_the_linear_scans_object(pa, n, seed, bounces, steal_flag):
+    """The BVH only prunes (pt_bvh.hpp): with and without it the same object is
+    struck on every segment, so canvases, executed searches and fp64 primary
+    hits are equal bit for bit (closestObjectTo, src/Lib.hs:81-98, is the scan)."""
+    objs = pa.random_disk_scene(n, seed)
+    H, W, spp = 72, 56, 5
+    out = []
+    for flags in (steal_flag, steal_flag | pa.PT_FLAG_NO_BVH):
+        with pa.Renderer(pa.Params(H, W, 60.0, spp, bounces), objs, seed=3, flags=flags) as r:
+            r.trace(2)
+            r.trace(spp - 2)
+            out.append((r.read_sum_f32(), r.segments, r.primary_hits()))
+    (a, sa, pa_), (b, sb, pb) = out
+    assert sa == sb
+    assert np.array_equal(a, b)
+    for x, y in zip(pa_, pb):
+        assert np.array_equal(x, y)
+    if n >= 300:                                           # 2 % of the objects are lights
+        assert a.sum() > 0
+
+
+def test_spatial_index_with_coincident_and_degenerate_disks(pa):
+    """Exact duplicates (ties go to the lower index), zero and negative radii,
+    a zero normal: the index must not change what the scan finds."""
+    base = pa.random_disk_scene(60, 31)
+    objs = list(base)
+    d = base[5]
+    objs += [pa.Object(d.color, 0.0, False, pa.Disk(d.form.center, d.form.normal, d.form.radius), "dup of 5")] * 3
+    objs += [pa.Object((1, 1, 1), 0.0, False, pa.Disk((0.0, 0.0, 300.0), (0.0, 0.0, -1.0), 0.0), "r = 0"),
+             pa.Object((1, 1, 1), 0.0, False, pa.Disk((10.0, 0.0, 300.0), (0.0, 0.0, -1.0), -5.0), "r < 0"),
+             pa.Object((1, 1, 1), 0.0, False, pa.Disk((20.0, 0.0, 300.0), (0.0, 0.0, 0.0), 30.0), "n = 0")]
+    H, W, spp = 64, 64, 4
+    res = []
+    for flags in (0, pa.PT_FLAG_NO_BVH):
+        with pa.Renderer(pa.Params(H, W, 60.0, spp, 6), objs, seed=9, flags=flags) as r:
+            r.trace(spp)
+            res.append((r.read_sum_f32(), r.segments, r.primary_hits()[0]))
+    assert res[0][1] == res[1][1]
+    assert np.array_equal(res[0][0], res[1][0])
+    assert np.array_equal(res[0][2], res[1][2])
+    assert not np.isin(res[0][2], [60, 61, 62]).any()       # a duplicate never wins over object 5
