@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpt.so")
+LIB_PATH = os.environ.get("PT_LIBPT_PATH") or os.path.join(_HERE, "libpt.so")    # override: A/B runs of another build
 
 PT_OK = 0
 PT_ERR_INVALID, PT_ERR_NO_DEVICE, PT_ERR_HIP, PT_ERR_NO_SCENE, PT_ERR_LIMIT = -1, -2, -3, -4, -5

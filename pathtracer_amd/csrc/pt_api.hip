@@ -29,7 +29,7 @@ struct pt_ctx {
     float4 *d_bvh_nodes = nullptr;               // spatial index over the finite forms (pt_bvh.hpp), or null
     int32_t *d_bvh_prims = nullptr;
     float4 *d_bvh_geom = nullptr;
-    int n_nodes = 0, n_unbounded = 0;
+    int n_nodes = 0, n_unbounded = 0, bvh_depth = 0;
     uint8_t *d_rgb = nullptr;
     int n_obj = 0;
     bool has_specular = false;
@@ -305,7 +305,9 @@ int pt_scene_upload(pt_ctx *c, const pt_object *objs, int32_t n)
         if ((int)finite.size() >= BVH_MIN_FINITE && std::isfinite(extent)) {
             // the device's slab test and ray arithmetic are fp32: a few ulp of the largest
             // coordinate (1.2e-7 * extent each); the pad is ~100 times that
-            BvhBuilder(boxes, finite, 2e-5 * extent + 1e-30).build(bvh, bvh.n_unbounded);
+            BvhBuilder builder(boxes, finite, 2e-5 * extent + 1e-30);
+            builder.build(bvh, bvh.n_unbounded);
+            c->bvh_depth = builder.max_depth;
             PT_HIP(c, hipMalloc((void **)&c->d_bvh_nodes, bvh.nodes.size() * sizeof(BvhNode)));
             PT_HIP(c, hipMalloc((void **)&c->d_bvh_prims, bvh.prims.size() * sizeof(int32_t)));
             PT_HIP(c, hipMemcpy(c->d_bvh_nodes, bvh.nodes.data(), bvh.nodes.size() * sizeof(BvhNode), hipMemcpyHostToDevice));
@@ -333,7 +335,7 @@ static void scene_args(const pt_ctx *c, TraceArgs &a)
     a.camera_depth = c->p.camera_depth;
     a.n_obj = c->n_obj; a.height = c->p.height; a.width = c->p.width;
     a.bvh_nodes = c->d_bvh_nodes; a.bvh_prims = c->d_bvh_prims; a.bvh_geom = c->d_bvh_geom;
-    a.n_nodes = c->n_nodes; a.n_unbounded = c->n_unbounded;
+    a.n_nodes = c->n_nodes; a.n_unbounded = c->n_unbounded; a.bvh_depth = c->bvh_depth;
 }
 
 int pt_trace(pt_ctx *c, int32_t iters)

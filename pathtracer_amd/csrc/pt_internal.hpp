@@ -43,6 +43,7 @@ struct TraceArgs {
     const int32_t *bvh_prims;          // [unbounded objects..., finite objects in leaf order...]
     const float4  *bvh_geom;           // geometry records in bvh_prims order (3 float4 each, object index in [2].w), padded
     int      n_nodes;
+    int      bvh_depth;                // deepest leaf: the walk's stack holds at most this many far children
     int      n_unbounded;
 };
 

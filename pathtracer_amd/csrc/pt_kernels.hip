@@ -22,9 +22,6 @@
 //   an LDS copy staged once per workgroup.
 #include "pt_internal.hpp"
 
-#ifndef PT_EXP
-#define PT_EXP 0
-#endif
 
 #include <type_traits>
 
@@ -150,13 +147,17 @@ __device__ __forceinline__ void closest(const TraceArgs &a, const StaticGeom<NS>
         for (int u = 0; u < a.n_unbounded; ++u) test(g[3 * u], g[3 * u + 1], g[3 * u + 2], true);
         bvh_walk(a.bvh_nodes, o.x, o.y, o.z, v.x, v.y, v.z, stack, stride,
                  [&](int first, int cnt) {
-                     float4 r[BVH_LEAF_SLOTS][3];
+#pragma unroll 1
+                     for (int h = 0; h < BVH_LEAF_SLOTS; h += 2) {
+                         float4 r[2][3];
 #pragma unroll
-                     for (int q = 0; q < BVH_LEAF_SLOTS; ++q) {           // the list is padded: slots past cnt are loadable
-                         r[q][0] = g[3 * (first + q)]; r[q][1] = g[3 * (first + q) + 1]; r[q][2] = g[3 * (first + q) + 2];
+                         for (int q = 0; q < 2; ++q) {
+                             r[q][0] = g[3 * (first + h + q)]; r[q][1] = g[3 * (first + h + q) + 1]; r[q][2] = g[3 * (first + h + q) + 2];
+                         }
+#pragma unroll
+                         for (int q = 0; q < 2; ++q) test(r[q][0], r[q][1], r[q][2], h + q < cnt);
+                         if (h + 2 >= cnt) break;
                      }
-#pragma unroll
-                     for (int q = 0; q < BVH_LEAF_SLOTS; ++q) test(r[q][0], r[q][1], r[q][2], q < cnt);
                  },
                  [&]() { return bt; });
         key_result(best, best_key, best_t);
@@ -229,8 +230,8 @@ template <int NS, bool REUSE, bool SPEC>
 __global__ __launch_bounds__(NS == -1 ? TILED_BLOCK : TRACE_BLOCK) void trace_kernel(TraceArgs a, StaticGeom<NS> sg)
 {
     constexpr int BLOCK = NS == -1 ? TILED_BLOCK : TRACE_BLOCK;
-    __shared__ int s_stack[(NS == -2 ? BVH_STACK_ENTRIES : 1) * (NS == -2 ? BLOCK : 1)];   // BVH walk: [entry][lane]
-    int *const stack = NS == -2 ? &s_stack[threadIdx.x] : nullptr;
+    // BVH walk: per-lane stack [entry][lane] in dynamic LDS, sized by the launcher from the tree's depth
+    int *const stack = NS == -2 ? reinterpret_cast<int *>(s_tile) + threadIdx.x : nullptr;
     bool lockstep = false;
     if constexpr (NS == -1) {
         lockstep = a.n_obj > a.tile_objs;
@@ -413,29 +414,11 @@ __global__ __launch_bounds__(NS == -2 ? 64 : TRACE_BLOCK) void trace_steal_kerne
     // atomics in the loop hipcc otherwise stops proving the list unclobbered and
     // turns the wave-uniform s_load stream into per-lane vector loads.
     a.geom = geom_ro;
-    static_assert(NS >= 0 || NS == -2, "work sharing is built for the SGPR, scalar-stream and BVH object lists");
-    if constexpr (NS > 0) {
-        auto fv = [](float &x) { x = __uint_as_float(to_vgpr(__float_as_uint(x))); };
-#pragma unroll
-        for (int k = 0; k < NS; ++k) {
-#if PT_EXP & 8
-            fv(sg.g[k][2].x); fv(sg.g[k][2].y); fv(sg.g[k][2].z);                     // disk centre
-#endif
-#if PT_EXP & 16
-            fv(sg.g[k][0].x); fv(sg.g[k][0].y); fv(sg.g[k][0].z); fv(sg.g[k][0].w);   // n_raw, A
-#endif
-#if PT_EXP & 32
-            fv(sg.g[k][1].x); fv(sg.g[k][1].y); fv(sg.g[k][1].z);                     // n_hat
-#endif
-#if PT_EXP & 64
-            fv(sg.g[k][0].w);                                                         // A only
-#endif
-        }
-    }
-    constexpr int BLOCK = NS == -2 ? 64 : TRACE_BLOCK;      // BVH walks diverge: one wave per workgroup, 8-KB stack
+    static_assert(NS == 0 || NS == -2, "scalar-stream and BVH object lists; small scenes use trace_static_kernel");
+    constexpr int BLOCK = NS == -2 ? 64 : TRACE_BLOCK;      // BVH walks diverge: one wave per workgroup
     constexpr int MAT_LDS_STRIDE = 5;
-    __shared__ int s_stack[(NS == -2 ? BVH_STACK_ENTRIES : 1) * (NS == -2 ? BLOCK : 1)];   // BVH walk: [entry][lane]
-    int *const stack = NS == -2 ? &s_stack[threadIdx.x] : nullptr;
+    // BVH walk: per-lane stack [entry][lane] in dynamic LDS, sized by the launcher from the tree's depth
+    int *const stack = NS == -2 ? reinterpret_cast<int *>(s_tile) + threadIdx.x : nullptr;
     __shared__ float4   s_mat[(NS > 0 ? NS : 1) * MAT_LDS_STRIDE];
     __shared__ uint32_t s_next[BLOCK];          // per pixel: next sample (launch-local index) not started
     __shared__ float4   s_pix[BLOCK * 3];       // per pixel: P0, d0, colour0, idx0, e0
@@ -490,16 +473,10 @@ __global__ __launch_bounds__(NS == -2 ? 64 : TRACE_BLOCK) void trace_steal_kerne
     uint32_t gs = a.sample_begin;
     bool alive = traced;                                   // has a path in flight
 
-#if PT_EXP & 1
     const PhiloxRegs pregs = philox_regs(a.seed);
-#endif
     auto scatter = [&](int idx, float e, f3 din, int bounce) -> f3 {
         uint32_t r0, r1;
-#if PT_EXP & 1
         philox2x32_10_pre_v((uint32_t)(pre >> 32), (uint32_t)pre, (gs << 6) | (uint32_t)bounce, pregs, r0, r1);
-#else
-        philox2x32_10_pre((uint32_t)(pre >> 32), (uint32_t)pre, (gs << 6) | (uint32_t)bounce, a.seed, r0, r1);
-#endif
         if constexpr (SPEC) {
             if (e < 0.f) {                                 // _reflective (src/Lib.hs:110)
                 const float4 m3 = mat(idx, 3);
@@ -515,28 +492,16 @@ __global__ __launch_bounds__(NS == -2 ? 64 : TRACE_BLOCK) void trace_steal_kerne
         int k; float t;
         closest<NS>(a, sg, o, d, last, k, t, stack, BLOCK);
         const bool live = decltype(all_alive)::value ? true : alive;
-#if PT_EXP & 4
         if (!decltype(all_alive)::value) segs += live ? 1 : 0;      // phase 1 counts its trips wave-uniformly
-#else
-        segs += live ? 1 : 0;
-#endif
         const bool hit = k >= 0;
         const float4 m0 = mat(hit ? k : 0, 0);
         bool terminal = live && (!hit || (m0.w > 0.f) || (b + 1 >= B));
-#if PT_EXP & 2
         {                                                  // emittance * pixel (src/Lib.hs:74)
             const float E = (live && hit) ? fmaxf(m0.w, 0.f) : 0.f;   // e <= 0: not a light
             acc.x = fmaf(E, thr.x, acc.x);
             acc.y = fmaf(E, thr.y, acc.y);
             acc.z = fmaf(E, thr.z, acc.z);
         }
-#else
-        if (terminal && hit && (m0.w > 0.f)) {             // emittance * pixel (src/Lib.hs:74)
-            acc.x = fmaf(m0.w, thr.x, acc.x);
-            acc.y = fmaf(m0.w, thr.y, acc.y);
-            acc.z = fmaf(m0.w, thr.z, acc.z);
-        }
-#endif
         draw(terminal);                                    // may clear or set `terminal` (= restart from cP0)
         int idx = terminal ? cidx : k;
         if (!decltype(all_alive)::value) idx = max(idx, 0);   // a pathless lane's garbage index stays in range
@@ -568,9 +533,7 @@ __global__ __launch_bounds__(NS == -2 ? 64 : TRACE_BLOCK) void trace_steal_kerne
             alive = sloc < n;
             trips += 1;
         } while (__ballot(alive) == everyone);
-#if PT_EXP & 4
         segs += trips;
-#endif
     }
     // A lane that has just left phase 1 restarted a path that does not exist
     // (sloc == n); it enters phase 2 pathless.
@@ -901,9 +864,9 @@ static hipError_t launch_trace_ns(TraceArgs a, const float4 *geom_host, bool reu
         a.tile_objs = a.n_obj < TILE_OBJECTS ? a.n_obj : TILE_OBJECTS;
         smem = (size_t)a.tile_objs * 3 * sizeof(float4);
     }
+    if (NS == -2) smem = (size_t)(a.bvh_depth + 1) * TRACE_BLOCK * sizeof(int);
     const int npix = a.height * a.width;
     const dim3 grid((npix + BLOCK - 1) / BLOCK), block(BLOCK);
-#if !(PT_EXP & 128)
     if constexpr (NS > 0) {
         if (steal && reuse) {
             const dim3 sgrid((npix + STATIC_BLOCK - 1) / STATIC_BLOCK), sblock(STATIC_BLOCK);
@@ -912,13 +875,13 @@ static hipError_t launch_trace_ns(TraceArgs a, const float4 *geom_host, bool reu
             return hipGetLastError();
         }
     }
-#endif
-    if constexpr (NS >= 0 || NS == -2) {
+    if constexpr (NS == 0 || NS == -2) {
         if (steal && reuse) {
             constexpr int SB = NS == -2 ? 64 : TRACE_BLOCK;
             const dim3 tgrid((npix + SB - 1) / SB), tblock(SB);
-            if (spec) hipLaunchKernelGGL((trace_steal_kernel<NS, true>), tgrid, tblock, 0, s, a, sg, a.geom);
-            else      hipLaunchKernelGGL((trace_steal_kernel<NS, false>), tgrid, tblock, 0, s, a, sg, a.geom);
+            const size_t ssm = NS == -2 ? (size_t)(a.bvh_depth + 1) * SB * sizeof(int) : 0;
+            if (spec) hipLaunchKernelGGL((trace_steal_kernel<NS, true>), tgrid, tblock, ssm, s, a, sg, a.geom);
+            else      hipLaunchKernelGGL((trace_steal_kernel<NS, false>), tgrid, tblock, ssm, s, a, sg, a.geom);
             return hipGetLastError();
         }
     }
@@ -947,7 +910,7 @@ hipError_t launch_trace(const TraceArgs &a, const float4 *geom_host, bool reuse,
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void primary_kernel(TraceArgs a, int32_t *idx, double *t, double *normal)
 {
-    __shared__ int s_stack[BVH_STACK_ENTRIES * 256];
+    int *const s_stack = reinterpret_cast<int *>(s_tile);     // (bvh_depth + 1) * 256 entries, dynamic
     const int H = a.height, W = a.width;
     const int pixel = blockIdx.x * 256 + threadIdx.x;
     if (pixel >= H * W) return;
@@ -964,7 +927,8 @@ __global__ __launch_bounds__(256) void primary_kernel(TraceArgs a, int32_t *idx,
 hipError_t launch_primary(const TraceArgs &a, int32_t *idx, double *t, double *normal, hipStream_t s)
 {
     const int npix = a.height * a.width;
-    hipLaunchKernelGGL(primary_kernel, dim3((npix + 255) / 256), dim3(256), 0, s, a, idx, t, normal);
+    hipLaunchKernelGGL(primary_kernel, dim3((npix + 255) / 256), dim3(256),
+                       a.n_nodes > 0 ? (size_t)(a.bvh_depth + 1) * 256 * sizeof(int) : 0, s, a, idx, t, normal);
     return hipGetLastError();
 }
 
