@@ -40,12 +40,13 @@ struct Params {
 };
 
 struct Form {                                           // src/Object.hs:51-56
-    enum Kind { InfinitePlane = PT_INFINITE_PLANE, Disk = PT_DISK } kind;
+    enum Kind { InfinitePlane = PT_INFINITE_PLANE, Disk = PT_DISK, Sphere = PT_SPHERE /* extension, src/Object.hs:191-194 is a TODO */ } kind;
     Triple point;      // _point | _center
     Triple normal;     // _normal
     double radius;     // _radius (Disk)
     static Form infinitePlane(Triple p, Triple n) { return Form{InfinitePlane, p, n, 0.0}; }
     static Form disk(Triple c, Triple n, double r) { return Form{Disk, c, n, r}; }
+    static Form sphere(Triple c, double r) { return Form{Sphere, c, Triple{0, 0, 0}, r}; }
 };
 
 struct Object {                                         // src/Object.hs:30-36

@@ -40,17 +40,24 @@ typedef enum {
     PT_ERR_LIMIT      = -5    /* a documented limit exceeded (objects, samples, bounces) */
 } pt_status;
 
-/* Form constructors (src/Object.hs:51-56).  PT_SPHERE is an extension the
- * reference only lists as a TODO (src/Object.hs:191-194); it has no reference
- * parity. */
-enum { PT_INFINITE_PLANE = 0, PT_DISK = 1 };
+/* Form constructors (src/Object.hs:51-56).  PT_SPHERE is an EXTENSION: the
+ * reference only lists it as a TODO (src/Object.hs:191-194), so it has no
+ * reference parity; this comment is its definition.  point = centre c,
+ * radius = r > 0 (else never hit), normal unused.  For a ray o + t v (v not
+ * unit, t a parameter), with oc = o - c:
+ *     m = (oc.v)/(v.v);   l = oc - m v;   no hit unless l.l <= r^2;
+ *     h = sqrt((r^2 - l.l)/(v.v));   t = -m - h if that is positive, else -m + h;
+ * then distanceFrom's guard 0 < t < Inf (src/Object.hs:159).  The normal at a
+ * hit point p is (p - c)/r, outward, never flipped toward the ray (as for the
+ * reference's forms); diffuse and specular scatter use it as they use _normal. */
+enum { PT_INFINITE_PLANE = 0, PT_DISK = 1, PT_SPHERE = 2 };
 
 /* One Object with its Form flattened (src/Object.hs:30-36, :51-56).  Doubles,
  * as the Haskell records hold; the library converts to its fp32 SoA layout at
  * upload.  _name is not carried: the reference uses it only inside Eq Object
  * (src/Object.hs:38-40), which the device replaces by index identity. */
 typedef struct {
-    int32_t kind;          /* PT_INFINITE_PLANE | PT_DISK                      */
+    int32_t kind;          /* PT_INFINITE_PLANE | PT_DISK | PT_SPHERE (extension: point = centre, radius; normal unused) */
     int32_t reflective;    /* _reflective  (src/Object.hs:33)                  */
     double  point[3];      /* _point / _center (src/Object.hs:52,55)           */
     double  normal[3];     /* _normal, raw, not normalised (src/Object.hs:53,56) */

@@ -211,9 +211,40 @@ int o_distance_from_prime(o_vec3 origin, o_vec3 vector, const o_object *f, doubl
         *t = d;
         return 1;
     }
+    case O_SPHERE: {
+        /* EXTENSION -- the reference only lists "add spheres" as a TODO
+         * (src/Object.hs:191-194), so there is nothing to be in parity with: this
+         * text is the definition, and the device's fp64 primary pass follows it
+         * operation for operation.  Centre p, radius r; the normal field is unused.
+         * With oc = origin - p and vector v (not unit):
+         *   m = (oc.v)/(v.v);  l = oc - m v (the part of oc across the ray);
+         *   no hit unless l.l <= r^2;  h = sqrt((r^2 - l.l)/(v.v));
+         *   t = -m - h if that is positive, else -m + h (origin inside the sphere).
+         * The caller's guard (0 < t < Inf) does the rest. */
+        o_vec3 oc = vsub(origin, p);
+        double a = o_dot(vector, vector);
+        double m = o_dot(oc, vector) / a;
+        o_vec3 l = vsub(oc, vscale(m, vector));
+        double r2 = f->radius * f->radius;
+        double d2 = o_dot(l, l);
+        if (!(f->radius > 0.0) || !(d2 <= r2)) return 0;
+        double h = sqrt((r2 - d2) / a);
+        double t1 = -m - h;
+        *t = (0.0 < t1) ? t1 : -m + h;
+        return 1;
+    }
     default:
         return 0;   /* no such Form in the reference (src/Object.hs:51-61) */
     }
+}
+
+/* getNormal (src/Object.hs:180-183) returns the form's stored _normal.  A sphere
+ * (extension) has none: its normal at a surface point is (point - centre)/radius,
+ * outward, never flipped toward the ray (as for the other forms). */
+o_vec3 o_normal_at(const o_object *f, o_vec3 point)
+{
+    if (f->kind != O_SPHERE) return v3(f->normal);
+    return vscale(1.0 / f->radius, vsub(point, v3(f->point)));
 }
 
 /* src/Object.hs:156-160 */
@@ -379,7 +410,9 @@ void o_primary_hits(const o_params *p, const o_object *objs, int n,
             int k = o_closest_object_to(objs, n, zero, o_primary_direction(p, i, j), -1, &d);
             idx[px] = k;
             t[px] = (k >= 0) ? d : 0.0;
-            for (int c = 0; c < 3; ++c) normal[px * 3 + c] = (k >= 0) ? objs[k].normal[c] : 0.0;
+            o_vec3 nr = { 0, 0, 0 };
+            if (k >= 0) nr = o_normal_at(&objs[k], o_march(zero, o_primary_direction(p, i, j), d));
+            normal[px * 3 + 0] = nr.x; normal[px * 3 + 1] = nr.y; normal[px * 3 + 2] = nr.z;
         }
 }
 
@@ -429,7 +462,7 @@ static o_vec3 terminal_color(const o_params *p, const o_object *objs, int n,
         o_vec3 hit = o_march(origin, vector, t);
         double u1, u2;
         draw2(d, &u1, &u2);
-        o_vec3 nrm = v3(o->normal);
+        o_vec3 nrm = o_normal_at(o, hit);
         o_vec3 nv = o->reflective ? o_specular_u(u1, u2, 40.0, vector, nrm)   /* :110 */
                                   : o_diffuse_u(u1, u2, nrm);                 /* :111 */
         pixel = vmul(pixel, v3(o->color));                                    /* :79 */

@@ -66,6 +66,8 @@ int o_default_scene(o_object *out4);
 /* distanceFrom' / distanceFrom (src/Object.hs:156-177).  Return 1 and *t when
  * the Maybe is Just, 0 when Nothing. */
 int o_distance_from_prime(o_vec3 origin, o_vec3 vector, const o_object *form, double *t);
+/* getNormal (src/Object.hs:180-183); for the O_SPHERE extension the outward normal at `point`. */
+o_vec3 o_normal_at(const o_object *form, o_vec3 point);
 int o_distance_from(o_vec3 origin, o_vec3 vector, const o_object *form, double *t);
 o_vec3 o_march(o_vec3 origin, o_vec3 vector, double t);       /* src/Object.hs:151-153 */
 

@@ -109,11 +109,29 @@ void flatten_object(const pt_object &ob, float4 *geom3, float4 *mat4, double *pr
     const double A = (0.0 + p.x * n.x + p.y * n.y) + p.z * n.z;
     const bool disk = ob.kind == PT_DISK;
     const float inf = std::numeric_limits<float>::infinity();
-    // a disk with a negative radius can never satisfy distance < radius
-    const float r2 = !disk ? inf : (ob.radius > 0.0 ? (float)(ob.radius * ob.radius) : -1.0f);
+    // a disk with a non-positive radius can never satisfy distance < radius (r2 = 0: nothing is below it;
+    // a NEGATIVE g1.w marks a sphere)
+    const float r2 = !disk ? inf : (ob.radius > 0.0 ? (float)(ob.radius * ob.radius) : 0.0f);
     geom3[0] = make_float4((float)n.x, (float)n.y, (float)n.z, (float)A);
     geom3[1] = make_float4((float)nh.x, (float)nh.y, (float)nh.z, r2);
     geom3[2] = make_float4((float)p.x, (float)p.y, (float)p.z, 0.0f);
+    if (ob.kind == PT_SPHERE) {
+        // Extension (the reference's TODO, src/Object.hs:191-194).  A sphere that can never be hit
+        // (r <= 0 or NaN) becomes a plane record with a zero normal: t = NaN.
+        const bool live = ob.radius > 0.0;
+        geom3[0] = make_float4(0.f, 0.f, 0.f, 0.f);
+        geom3[1] = make_float4(0.f, 0.f, 0.f, live ? -(float)(ob.radius * ob.radius) : inf);
+        const float e = ob.emittance > 0.0 ? (float)ob.emittance : (ob.reflective ? -1.0f : 0.0f);
+        mat4[0] = make_float4((float)ob.color[0], (float)ob.color[1], (float)ob.color[2], e);
+        mat4[1] = make_float4((float)p.x, (float)p.y, (float)p.z, live ? (float)(1.0 / ob.radius) : 0.f);
+        mat4[2] = make_float4(0.f, 0.f, 0.f, 0.f);
+        mat4[3] = make_float4(std::numeric_limits<float>::quiet_NaN(), 0.f, 0.f, 0.f);
+        prim[0] = p.x; prim[1] = p.y; prim[2] = p.z;
+        for (int q = 3; q < 9; ++q) prim[q] = 0.0;
+        prim[9] = ob.radius;
+        prim[10] = 2.0;
+        return;
+    }
 
     // M = |n| * rotateAbs(., theta', phi')  (src/Util.hs:131-145)
     double th, ph;
@@ -248,7 +266,7 @@ int pt_scene_upload(pt_ctx *c, const pt_object *objs, int32_t n)
     if (!objs) return fail(c, PT_ERR_INVALID, "pt_scene_upload: null objects");
     if (n < 1 || n > MAX_OBJECTS) return fail(c, PT_ERR_LIMIT, "pt_scene_upload: need 1 <= n <= 65536");
     for (int k = 0; k < n; ++k)
-        if (objs[k].kind != PT_INFINITE_PLANE && objs[k].kind != PT_DISK)
+        if (objs[k].kind != PT_INFINITE_PLANE && objs[k].kind != PT_DISK && objs[k].kind != PT_SPHERE)
             return fail(c, PT_ERR_INVALID, "pt_scene_upload: unknown Form kind");
 
     // 8 trailing records that can never be hit (n = 0 gives t = NaN): the
@@ -266,6 +284,8 @@ int pt_scene_upload(pt_ctx *c, const pt_object *objs, int32_t n)
         flatten_object(objs[k], &geom[(size_t)k * 3], &mat[(size_t)k * 4], &prim[(size_t)k * PRIM_DOUBLES]);
         // only a non-emissive reflective object ever scatters specularly (src/Lib.hs:74-78)
         spec = spec || (objs[k].reflective && !(objs[k].emittance > 0.0));
+        // a sphere's bounce builds its rotation per hit: the same general-scatter kernels
+        spec = spec || objs[k].kind == PT_SPHERE;
     }
     PT_HIP(c, hipStreamSynchronize(c->stream));
     if (c->d_geom) { (void)hipFree(c->d_geom); c->d_geom = nullptr; }
@@ -293,10 +313,11 @@ int pt_scene_upload(pt_ctx *c, const pt_object *objs, int32_t n)
         Bvh bvh;
         double extent = 0.0;
         for (int k = 0; k < n; ++k) {
-            if (objs[k].kind != PT_DISK) { bvh.prims.push_back(k); continue; }
+            if (objs[k].kind == PT_INFINITE_PLANE) { bvh.prims.push_back(k); continue; }
             const double *pr = &prim[(size_t)k * PRIM_DOUBLES];
             const double r = objs[k].radius > 0.0 ? objs[k].radius : 0.0;      // r <= 0 or NaN: never hit
-            boxes[(size_t)k] = disk_bounds(pr, pr + 6, r);
+            const double zero3[3] = {0.0, 0.0, 0.0};                           // a sphere: the full +-r box
+            boxes[(size_t)k] = disk_bounds(pr, objs[k].kind == PT_SPHERE ? zero3 : pr + 6, r);
             for (int a = 0; a < 3; ++a)
                 extent = std::max(extent, std::max(std::fabs(boxes[(size_t)k].lo[a]), std::fabs(boxes[(size_t)k].hi[a])));
             finite.push_back(k);
@@ -595,7 +616,7 @@ int pt_dev_distance(pt_ctx *c, int32_t n, const pt_object *obj, const float *ori
 {
     if (int s = check_ctx(c)) return s;
     if (n < 1 || !obj || !origin || !vector || !t_out) return fail(c, PT_ERR_INVALID, "pt_dev_distance: bad argument");
-    if (obj->kind != PT_INFINITE_PLANE && obj->kind != PT_DISK)
+    if (obj->kind != PT_INFINITE_PLANE && obj->kind != PT_DISK && obj->kind != PT_SPHERE)
         return fail(c, PT_ERR_INVALID, "pt_dev_distance: unknown Form kind");
     float4 g[3], m[4]; double prim[PRIM_DOUBLES];
     flatten_object(*obj, g, m, prim);

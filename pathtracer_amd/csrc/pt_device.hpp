@@ -28,6 +28,8 @@ namespace pt {
 //   g2 = (c.x, c.y, c.z, 0)                    disk centre
 // so that  t = (A - o.n_raw) / (v.n_hat)  ==  ((p-o).n) / (v.normalize n)
 // (src/Object.hs:176-177, raw normal above and unit normal below kept).
+// Sphere (extension, no reference counterpart: src/Object.hs:191-194 is a TODO):
+//   g0 = 0, g1 = (0, 0, 0, -r^2)  -- a NEGATIVE g1.w marks the form --, g2 = (c.xyz, 0)
 constexpr int GEOM_FLOATS = 12;
 // Material record, 16 floats (4 x float4), read with a per-lane index:
 //   m0 = (color.r, color.g, color.b, e)   e > 0: emittance (light)
@@ -37,6 +39,8 @@ constexpr int GEOM_FLOATS = 12;
 //   m3 = (M22, n_hat.x, n_hat.y, n_hat.z) (src/Util.hs:114-145)
 // so a diffuse bounce reads m1, m2 (two 16-B LDS reads) and one dword of m3,
 // and only a specular bounce needs the unit normal.
+// Sphere: m1 = (c.xyz, 1/r), m3.x = NaN (the marker): the normal depends on the
+// hit point, so the bounce builds its rotation per hit (scatter_about).
 constexpr int MAT_FLOATS = 16;
 // fp64 record for the primary pass, 11 doubles:
 //   point[3], n_raw[3], n_hat[3] (normalize n, src/Triple.hs:66-69), radius, kind
@@ -190,26 +194,16 @@ __device__ __forceinline__ float asin_rev01(float x)
     return (1.5707963268f - acos_x) * 0.15915494309f;
 }
 
-// specular (src/Lib.hs:115-127) + rotateRel about the mirror direction
-// (src/Util.hs:140-145).  n_hat = normalize normal.  Direction length is
-// preserved (the reference rescales by norm2 vector').
-__device__ __forceinline__ f3 scatter_specular(f3 v, f3 nh, float u1, float u2, float noise_rev)
+// rotateRel (src/Util.hs:140-145) applied to the local direction l =
+// fromSphericalCoords theta phi: rotate l by the spherical angles of `axis` and
+// rescale by |axis|.  toSphericalCoords axis (src/Util.hs:114-122) in algebraic form:
+//   cos th' = a.z, sin th' = rho, cos ph' = a.x/rho, sin ph' = a.y/rho,
+// a = normalize axis, rho = sqrt(a.x^2 + a.y^2).
+__device__ __forceinline__ f3 rotate_rel_local(f3 l, f3 axis)
 {
-    const float dvn = dot3(v, nh);
-    const f3 vp = fma3(-2.0f * dvn, nh, v);                 // vector + (-2) * projection
-    const float len2 = dot3(v, v);
-    const float len  = __builtin_amdgcn_sqrtf(len2);
-    const float inv  = __builtin_amdgcn_rcpf(fmaxf(len, 1e-6f));   // normalize floors the norm at 1e-6
-    // angleWithSurface = 90 - acos |n_hat . v_hat|  ==  asin |n_hat . v_hat|
-    const float c = fminf(fabsf(dvn) * inv, 1.0f);
-    const float max_theta = fminf(asin_rev01(c), noise_rev);
-    const f3 l = local_dir(max_theta * u1, PHI_REV * u2);
-    // toSphericalCoords vector' (src/Util.hs:114-122) in algebraic form:
-    //   cos th' = a.z, sin th' = rho, cos ph' = a.x/rho, sin ph' = a.y/rho,
-    // a = normalize vector', rho = sqrt(a.x^2 + a.y^2).
-    const float lenp = __builtin_amdgcn_sqrtf(dot3(vp, vp));
-    const float invp = __builtin_amdgcn_rcpf(fmaxf(lenp, 1e-6f));
-    const f3 a = mk3(vp.x * invp, vp.y * invp, vp.z * invp);
+    const float lenp = __builtin_amdgcn_sqrtf(dot3(axis, axis));
+    const float invp = __builtin_amdgcn_rcpf(fmaxf(lenp, 1e-6f));   // normalize floors the norm at 1e-6
+    const f3 a = mk3(axis.x * invp, axis.y * invp, axis.z * invp);
     const float rho2 = fmaf(a.y, a.y, a.x * a.x);
     float ct, st, cp, sp;
     if (rho2 > 0.0f) {
@@ -230,10 +224,55 @@ __device__ __forceinline__ f3 scatter_specular(f3 v, f3 nh, float u1, float u2, 
     return mk3(x * lenp, y * lenp, z * lenp);
 }
 
+// specular (src/Lib.hs:115-127) + rotateRel about the mirror direction
+// (src/Util.hs:140-145).  n_hat = normalize normal.  Direction length is
+// preserved (the reference rescales by norm2 vector').
+__device__ __forceinline__ f3 scatter_specular(f3 v, f3 nh, float u1, float u2, float noise_rev)
+{
+    const float dvn = dot3(v, nh);
+    const f3 vp = fma3(-2.0f * dvn, nh, v);                 // vector + (-2) * projection
+    const float len2 = dot3(v, v);
+    const float len  = __builtin_amdgcn_sqrtf(len2);
+    const float inv  = __builtin_amdgcn_rcpf(fmaxf(len, 1e-6f));   // normalize floors the norm at 1e-6
+    // angleWithSurface = 90 - acos |n_hat . v_hat|  ==  asin |n_hat . v_hat|
+    const float c = fminf(fabsf(dvn) * inv, 1.0f);
+    const float max_theta = fminf(asin_rev01(c), noise_rev);
+    const f3 l = local_dir(max_theta * u1, PHI_REV * u2);
+    return rotate_rel_local(l, vp);
+}
+
+// diffuse (src/Lib.hs:129-132) about a normal that is not a per-object constant
+// (the Sphere extension): rotateRel theta phi normal, built per hit.
+__device__ __forceinline__ f3 scatter_diffuse_about(f3 normal, uint32_t r0, uint32_t r1)
+{
+    const float theta_rev = __uint_as_float((r0 & U1_MASK) | 0x3f800000u);
+    const float f = __uint_as_float((r1 & U2_MASK) | 0x3f800000u);
+    return rotate_rel_local(local_dir(theta_rev, fmaf(f, PHI_REV, -PHI_REV)), normal);
+}
+
+// Sphere (extension; the definition is in include/pt.h at PT_SPHERE): centre c,
+// r2 = r^2.  m = (oc.v)/(v.v); l = oc - m v; no hit unless l.l <= r2;
+// h = sqrt((r2 - l.l)/(v.v)); t = -m - h if positive, else -m + h.  NaN = no hit.
+__device__ __forceinline__ float sphere_t(f3 c, float r2, f3 o, f3 v)
+{
+    const f3 oc = mk3(o.x - c.x, o.y - c.y, o.z - c.z);
+    const float ia = __builtin_amdgcn_rcpf(dot3(v, v));
+    const float m = dot3(oc, v) * ia;
+    const f3 l = mk3(fmaf(-m, v.x, oc.x), fmaf(-m, v.y, oc.y), fmaf(-m, v.z, oc.z));
+    const float q = r2 - dot3(l, l);
+    const float h = __builtin_amdgcn_sqrtf(q * ia);           // q < 0 -> NaN -> no hit
+    const float t1 = -m - h;
+    return (t1 > 0.0f) ? t1 : (h - m);
+}
+
 // distanceFrom (src/Object.hs:156-177) for one object against one ray.
 // Returns t, or NaN where the reference returns Nothing.
 __device__ __forceinline__ float distance_from(float4 g0, float4 g1, float4 g2, f3 o, f3 v)
 {
+    if (g1.w < 0.0f) {                                         // Sphere (extension)
+        const float ts = sphere_t(mk3(g2.x, g2.y, g2.z), -g1.w, o, v);
+        return (__float_as_uint(ts) - 1u < 0x7f7fffffu) ? ts : __builtin_nanf("");
+    }
     const float num = fmaf(-o.z, g0.z, fmaf(-o.y, g0.y, fmaf(-o.x, g0.x, g0.w)));
     const float den = fmaf(v.z, g1.z, fmaf(v.y, g1.y, v.x * g1.x));
     // the trace kernel's form (closest_static): the -denorm_min addend turns t = +0
@@ -254,6 +293,52 @@ __device__ __forceinline__ float distance_from(float4 g0, float4 g1, float4 g2, 
 // contraction off.  prim = PRIM_DOUBLES doubles per object.
 struct PrimaryHit { int idx; double t; double dx, dy, dz; };
 
+// distanceFrom of object k for the primary ray (origin 0) + closestObjectTo's
+// update, in the reference's operation order (src/Object.hs:156-177; the Sphere
+// extension in the order include/pt.h states), contraction off.
+// An equal t keeps the lower index: Data.Vector.minimumBy's first-wins in any
+// visiting order (src/Lib.hs:84).
+__device__ __forceinline__ void primary_candidate(const double *__restrict__ prim, int k, PrimaryHit &h)
+{
+#pragma clang fp contract(off)
+    const double *p = prim + (size_t)k * PRIM_DOUBLES;
+    double t;
+    bool ok;
+    if (p[10] == 2.0) {                                       // Sphere (extension): o_distance_from_prime, O_SPHERE
+        const double ocx = 0.0 - p[0], ocy = 0.0 - p[1], ocz = 0.0 - p[2];
+        double a = 0.0;  a = a + h.dx * h.dx;  a = a + h.dy * h.dy;  a = a + h.dz * h.dz;
+        double b = 0.0;  b = b + ocx * h.dx;   b = b + ocy * h.dy;   b = b + ocz * h.dz;
+        const double m = b / a;
+        const double lx = ocx - m * h.dx, ly = ocy - m * h.dy, lz = ocz - m * h.dz;
+        const double r2 = p[9] * p[9];
+        double d2 = 0.0; d2 = d2 + lx * lx; d2 = d2 + ly * ly; d2 = d2 + lz * lz;
+        ok = (p[9] > 0.0) && (d2 <= r2);
+        const double hh = sqrt((r2 - d2) / a);
+        const double t1 = -m - hh;
+        t = (0.0 < t1) ? t1 : -m + hh;
+        ok = ok && (0.0 < t) && (t < (double)__builtin_inff());
+    } else {
+        // (point - origin) with origin = 0, then `dot` as a left fold from 0
+        double num = 0.0;
+        num = num + (p[0] - 0.0) * p[3];
+        num = num + (p[1] - 0.0) * p[4];
+        num = num + (p[2] - 0.0) * p[5];
+        double den = 0.0;
+        den = den + h.dx * p[6];
+        den = den + h.dy * p[7];
+        den = den + h.dz * p[8];
+        t = num / den;
+        ok = (0.0 < t) && (t < (double)__builtin_inff());
+        if (ok && p[10] != 0.0) {                             // Disk
+            const double px = 0.0 + t * h.dx - p[0];
+            const double py = 0.0 + t * h.dy - p[1];
+            const double pz = 0.0 + t * h.dz - p[2];
+            ok = sqrt(px * px + py * py + pz * pz) < p[9];
+        }
+    }
+    if (ok && (h.idx < 0 || t < h.t || (t == h.t && k < h.idx))) { h.idx = k; h.t = t; }
+}
+
 __device__ inline PrimaryHit primary_hit_f64(const double *__restrict__ prim, int n,
                                              int H, int W, double camera_depth, int i, int j)
 {
@@ -266,27 +351,7 @@ __device__ inline PrimaryHit primary_hit_f64(const double *__restrict__ prim, in
     const double norm = (floor_ <= nrm) ? nrm : floor_;
     h.dx = ip / norm; h.dy = jp / norm; h.dz = camera_depth / norm;
     h.idx = -1; h.t = 0.0;
-    for (int k = 0; k < n; ++k) {
-        const double *p = prim + (size_t)k * PRIM_DOUBLES;
-        // (point - origin) with origin = 0, then `dot` as a left fold from 0
-        double num = 0.0;
-        num = num + (p[0] - 0.0) * p[3];
-        num = num + (p[1] - 0.0) * p[4];
-        num = num + (p[2] - 0.0) * p[5];
-        double den = 0.0;
-        den = den + h.dx * p[6];
-        den = den + h.dy * p[7];
-        den = den + h.dz * p[8];
-        const double t = num / den;
-        bool ok = (0.0 < t) && (t < (double)__builtin_inff());
-        if (ok && p[10] != 0.0) {                             // Disk
-            const double px = 0.0 + t * h.dx - p[0];
-            const double py = 0.0 + t * h.dy - p[1];
-            const double pz = 0.0 + t * h.dz - p[2];
-            ok = sqrt(px * px + py * py + pz * pz) < p[9];
-        }
-        if (ok && (h.idx < 0 || t < h.t)) { h.idx = k; h.t = t; }
-    }
+    for (int k = 0; k < n; ++k) primary_candidate(prim, k, h);
     return h;
 }
 
@@ -363,27 +428,7 @@ __device__ inline PrimaryHit primary_hit_f64_bvh(const double *__restrict__ prim
     const double norm = (floor_ <= nrm) ? nrm : floor_;
     h.dx = ip / norm; h.dy = jp / norm; h.dz = camera_depth / norm;
     h.idx = -1; h.t = 0.0;
-    auto test = [&](int k) {
-        const double *p = prim + (size_t)k * PRIM_DOUBLES;
-        double num = 0.0;
-        num = num + (p[0] - 0.0) * p[3];
-        num = num + (p[1] - 0.0) * p[4];
-        num = num + (p[2] - 0.0) * p[5];
-        double den = 0.0;
-        den = den + h.dx * p[6];
-        den = den + h.dy * p[7];
-        den = den + h.dz * p[8];
-        const double t = num / den;
-        bool ok = (0.0 < t) && (t < (double)__builtin_inff());
-        if (ok && p[10] != 0.0) {                             // Disk
-            const double px = 0.0 + t * h.dx - p[0];
-            const double py = 0.0 + t * h.dy - p[1];
-            const double pz = 0.0 + t * h.dz - p[2];
-            ok = sqrt(px * px + py * py + pz * pz) < p[9];
-        }
-        // minimumBy keeps the earlier element on equal t (src/Lib.hs:84)
-        if (ok && (h.idx < 0 || t < h.t || (t == h.t && k < h.idx))) { h.idx = k; h.t = t; }
-    };
+    auto test = [&](int k) { primary_candidate(prim, k, h); };
     for (int u = 0; u < n_unbounded; ++u) test(prims[u]);
     // the fp64 t is compared in fp32 by the slab test: widen it by one part in 2^20
     bvh_walk(nodes, 0.f, 0.f, 0.f, (float)h.dx, (float)h.dy, (float)h.dz, stack, stride,

@@ -38,9 +38,19 @@ __device__ __forceinline__ unsigned long long *seg_lane(unsigned long long *base
 // ---------------------------------------------------------------------------
 // closest-hit search (closestObjectTo, src/Lib.hs:81-98)
 // ---------------------------------------------------------------------------
+template <bool SPH>
 __device__ __forceinline__ void test_object(float4 g0, float4 g1, float4 g2, int k, f3 o, f3 v,
                                             int last, int &best, float &best_t)
 {
+    if constexpr (SPH) {
+        if (g1.w < 0.0f) {                      // wave-uniform: Sphere (extension); NaN = no hit fails every compare
+            const float ts = sphere_t(mk3(g2.x, g2.y, g2.z), -g1.w, o, v);
+            const bool oks = (ts > 0.0f) & (ts < best_t) & (k != last);
+            best = oks ? k : best;
+            best_t = oks ? ts : best_t;
+            return;
+        }
+    }
     // t = (A - o.n_raw) / (v.n_hat); every object operand is wave-uniform (SGPR)
     const float on  = fmaf(o.z, g0.z, fmaf(o.y, g0.y, o.x * g0.x));
     const float den = fmaf(v.z, g1.z, fmaf(v.y, g1.y, v.x * g1.x));
@@ -72,9 +82,20 @@ __device__ __forceinline__ void test_object(float4 g0, float4 g1, float4 g2, int
 constexpr uint32_t KEY_INVALID = 0xffffffffu;
 constexpr uint32_t KEY_LIMIT   = 0x7f7fffffu;   // bits(+Inf) - 1: keys below are finite positive t
 
+template <bool SPH>
 __device__ __forceinline__ void test_object_key(float4 g0, float4 g1, float4 g2, int k, f3 o, f3 v,
                                                 int last, int &best, uint32_t &best_key)
 {
+    if constexpr (SPH) {
+        if (g1.w < 0.0f) {                      // wave-uniform: Sphere (extension)
+            uint32_t keys = __float_as_uint(sphere_t(mk3(g2.x, g2.y, g2.z), -g1.w, o, v)) - 1u;
+            keys = (k == last) ? KEY_INVALID : keys;
+            const bool b = keys < best_key;
+            best = b ? k : best;
+            best_key = b ? keys : best_key;
+            return;
+        }
+    }
     const float on  = fmaf(o.z, g0.z, fmaf(o.y, g0.y, o.x * g0.x));
     const float den = fmaf(v.z, g1.z, fmaf(v.y, g1.y, v.x * g1.x));
     const float t = (g0.w - on) * __builtin_amdgcn_rcpf(den);
@@ -110,7 +131,7 @@ __device__ __forceinline__ PrimaryHit primary_hit(const TraceArgs &a, int pi, in
 // LDS tile of geometry records for the tiled kernel (NS == -1), dynamic size.
 extern __shared__ float4 s_tile[];
 
-template <int NS>
+template <int NS, bool SPH>
 __device__ __forceinline__ void closest(const TraceArgs &a, const StaticGeom<NS> &sg, f3 o, f3 v,
                                         int last, int &best, float &best_t, int *stack = nullptr, int stride = 0)
 {
@@ -132,13 +153,18 @@ __device__ __forceinline__ void closest(const TraceArgs &a, const StaticGeom<NS>
             const int k = __float_as_int(g2.w);
             const float onr = fmaf(o.z, g0.z, fmaf(o.y, g0.y, o.x * g0.x));
             const float den = fmaf(v.z, g1.z, fmaf(v.y, g1.y, v.x * g1.x));
-            const float t = (g0.w - onr) * __builtin_amdgcn_rcpf(den);
-            uint32_t key = __float_as_uint(t) - 1u;
-            key = (k == last || !on) ? KEY_INVALID : key;     // _lastStruck (src/Lib.hs:86-90)
+            float t = (g0.w - onr) * __builtin_amdgcn_rcpf(den);
             const float dx = fmaf(t, v.x, o.x) - g2.x;         // Disk (src/Object.hs:165-171); a plane has r2 = +Inf
             const float dy = fmaf(t, v.y, o.y) - g2.y;
             const float dz = fmaf(t, v.z, o.z) - g2.z;
-            key = (fmaf(dz, dz, fmaf(dy, dy, dx * dx)) < g1.w || g1.w == __builtin_inff()) ? key : KEY_INVALID;
+            bool inside = (fmaf(dz, dz, fmaf(dy, dy, dx * dx)) < g1.w) || (g1.w == __builtin_inff());
+            if constexpr (SPH) {                               // per lane here: both forms computed, one selected
+                const float ts = sphere_t(mk3(g2.x, g2.y, g2.z), -g1.w, o, v);
+                t = (g1.w < 0.0f) ? ts : t;
+                inside = inside || (g1.w < 0.0f);
+            }
+            uint32_t key = __float_as_uint(t) - 1u;
+            key = (k == last || !on || !inside) ? KEY_INVALID : key;     // _lastStruck (src/Lib.hs:86-90)
             const bool better = (key < best_key) | ((key == best_key) & (key < KEY_LIMIT) & (k < best));
             best = better ? k : best;
             best_key = better ? key : best_key;
@@ -179,7 +205,7 @@ __device__ __forceinline__ void closest(const TraceArgs &a, const StaticGeom<NS>
             }
 #pragma unroll 2
             for (int k = 0; k < cnt; ++k)
-                test_object_key(s_tile[3 * k + 0], s_tile[3 * k + 1], s_tile[3 * k + 2], base + k, o, v, last, best,
+                test_object_key<SPH>(s_tile[3 * k + 0], s_tile[3 * k + 1], s_tile[3 * k + 2], base + k, o, v, last, best,
                                 best_key);
         }
         key_result(best, best_key, best_t);
@@ -189,7 +215,7 @@ __device__ __forceinline__ void closest(const TraceArgs &a, const StaticGeom<NS>
         // the host pads the list to NS with objects that can never be hit
 #pragma unroll
         for (int k = 0; k < NS; ++k)
-            test_object(sg.g[k][0], sg.g[k][1], sg.g[k][2], k, o, v, last, best, best_t);
+            test_object<SPH>(sg.g[k][0], sg.g[k][1], sg.g[k][2], k, o, v, last, best, best_t);
     } else {
         // Large scenes: the records stream through the scalar cache from L2/HBM.
         // Scalar loads return out of order, so the only safe wait is
@@ -206,13 +232,13 @@ __device__ __forceinline__ void closest(const TraceArgs &a, const StaticGeom<NS>
         for (int k = 0; k < n; k += 4) {
             load(B0, g + 6); load(B1, g + 9);
             __builtin_amdgcn_sched_barrier(0);             // keep the prefetch ahead of the arithmetic
-            test_object_key(A0[0], A0[1], A0[2], k, o, v, last, best, best_key);
-            test_object_key(A1[0], A1[1], A1[2], k + 1, o, v, last, best, best_key);
+            test_object_key<SPH>(A0[0], A0[1], A0[2], k, o, v, last, best, best_key);
+            test_object_key<SPH>(A1[0], A1[1], A1[2], k + 1, o, v, last, best, best_key);
             g += 12;
             load(A0, g); load(A1, g + 3);
             __builtin_amdgcn_sched_barrier(0);
-            test_object_key(B0[0], B0[1], B0[2], k + 2, o, v, last, best, best_key);
-            test_object_key(B1[0], B1[1], B1[2], k + 3, o, v, last, best, best_key);
+            test_object_key<SPH>(B0[0], B0[1], B0[2], k + 2, o, v, last, best, best_key);
+            test_object_key<SPH>(B1[0], B1[1], B1[2], k + 3, o, v, last, best, best_key);
         }
         key_result(best, best_key, best_t);
     }
@@ -308,14 +334,20 @@ __global__ __launch_bounds__(NS == -1 ? TILED_BLOCK : TRACE_BLOCK) void trace_ke
     int last = -1, b = 0, s = 0;
     uint32_t gs = a.sample_begin;
 
-    auto scatter = [&](int idx, float e, f3 din, int bounce) -> f3 {
+    auto scatter = [&](int idx, float e, f3 din, int bounce, f3 at) -> f3 {
         uint32_t r0, r1;
         philox2x32_10((uint32_t)pc, (gs << 6) | (uint32_t)bounce, a.seed, r0, r1);
         if constexpr (SPEC) {
-            if (e < 0.f) {                                 // _reflective (src/Lib.hs:110)
-                const float4 m3 = mat(idx, 3);
-                return scatter_specular(din, mk3(m3.y, m3.z, m3.w), u_theta(r0), u_phi(r1), NOISE_REV);
+            const float4 m3 = mat(idx, 3);
+            f3 nrm = mk3(m3.y, m3.z, m3.w);
+            const bool sphere = m3.x != m3.x;              // NaN marks the Sphere extension: normal at the hit point
+            if (sphere) {
+                const float4 m1 = mat(idx, 1);
+                nrm = mk3((at.x - m1.x) * m1.w, (at.y - m1.y) * m1.w, (at.z - m1.z) * m1.w);
             }
+            if (e < 0.f)                                   // _reflective (src/Lib.hs:110)
+                return scatter_specular(din, nrm, u_theta(r0), u_phi(r1), NOISE_REV);
+            if (sphere) return scatter_diffuse_about(nrm, r0, r1);
         }
         float4 m1, m2; float m22;
         mat_rot(idx, m1, m2, m22);
@@ -324,7 +356,7 @@ __global__ __launch_bounds__(NS == -1 ? TILED_BLOCK : TRACE_BLOCK) void trace_ke
 
     if constexpr (REUSE) {
         if (n_my > 0) {
-            d = scatter(idx0, e0, d0, 0);
+            d = scatter(idx0, e0, d0, 0, P0);
             o = P0; last = idx0; thr = color0; b = 1;
         }
     }
@@ -338,7 +370,7 @@ __global__ __launch_bounds__(NS == -1 ? TILED_BLOCK : TRACE_BLOCK) void trace_ke
             if (!alive) break;
         }
         int k; float t;
-        closest<NS>(a, sg, o, d, last, k, t, stack, BLOCK);
+        closest<NS, SPEC>(a, sg, o, d, last, k, t, stack, BLOCK);
         segs += alive ? 1 : 0;
         const bool hit = k >= 0;
         const float4 m0 = mat(hit ? k : 0, 0);
@@ -363,7 +395,7 @@ __global__ __launch_bounds__(NS == -1 ? TILED_BLOCK : TRACE_BLOCK) void trace_ke
             thr = mk3(terminal ? color0.x : thr.x * m0.x,               // pixel * color (src/Lib.hs:79)
                       terminal ? color0.y : thr.y * m0.y,
                       terminal ? color0.z : thr.z * m0.z);
-            d = scatter(idx, e, din, bn);
+            d = scatter(idx, e, din, bn, hp);
             o = hp; last = idx; b = bn + 1;
         } else {
             if (terminal) {
@@ -372,7 +404,7 @@ __global__ __launch_bounds__(NS == -1 ? TILED_BLOCK : TRACE_BLOCK) void trace_ke
             } else {
                 const f3 hp = fma3(t, d, o);
                 thr = mk3(thr.x * m0.x, thr.y * m0.y, thr.z * m0.z);
-                d = scatter(k, m0.w, d, b);
+                d = scatter(k, m0.w, d, b, hp);
                 o = hp; last = k; b += 1;
             }
         }
@@ -474,14 +506,20 @@ __global__ __launch_bounds__(NS == -2 ? 64 : TRACE_BLOCK) void trace_steal_kerne
     bool alive = traced;                                   // has a path in flight
 
     const PhiloxRegs pregs = philox_regs(a.seed);
-    auto scatter = [&](int idx, float e, f3 din, int bounce) -> f3 {
+    auto scatter = [&](int idx, float e, f3 din, int bounce, f3 at) -> f3 {
         uint32_t r0, r1;
         philox2x32_10_pre_v((uint32_t)(pre >> 32), (uint32_t)pre, (gs << 6) | (uint32_t)bounce, pregs, r0, r1);
         if constexpr (SPEC) {
-            if (e < 0.f) {                                 // _reflective (src/Lib.hs:110)
-                const float4 m3 = mat(idx, 3);
-                return scatter_specular(din, mk3(m3.y, m3.z, m3.w), u_theta(r0), u_phi(r1), NOISE_REV);
+            const float4 m3 = mat(idx, 3);
+            f3 nrm = mk3(m3.y, m3.z, m3.w);
+            const bool sphere = m3.x != m3.x;              // NaN marks the Sphere extension: normal at the hit point
+            if (sphere) {
+                const float4 m1 = mat(idx, 1);
+                nrm = mk3((at.x - m1.x) * m1.w, (at.y - m1.y) * m1.w, (at.z - m1.z) * m1.w);
             }
+            if (e < 0.f)                                   // _reflective (src/Lib.hs:110)
+                return scatter_specular(din, nrm, u_theta(r0), u_phi(r1), NOISE_REV);
+            if (sphere) return scatter_diffuse_about(nrm, r0, r1);
         }
         return scatter_diffuse_bits(mat(idx, 1), mat(idx, 2), mat(idx, 3).x, r0, r1);   // src/Lib.hs:111
     };
@@ -490,7 +528,7 @@ __global__ __launch_bounds__(NS == -2 ? 64 : TRACE_BLOCK) void trace_steal_kerne
     // `all_alive` (compile-time): phase 1 only runs while every lane has a path.
     auto trip = [&](auto all_alive, auto &&draw) {
         int k; float t;
-        closest<NS>(a, sg, o, d, last, k, t, stack, BLOCK);
+        closest<NS, SPEC>(a, sg, o, d, last, k, t, stack, BLOCK);
         const bool live = decltype(all_alive)::value ? true : alive;
         if (!decltype(all_alive)::value) segs += live ? 1 : 0;      // phase 1 counts its trips wave-uniformly
         const bool hit = k >= 0;
@@ -514,11 +552,11 @@ __global__ __launch_bounds__(NS == -2 ? 64 : TRACE_BLOCK) void trace_steal_kerne
         thr = mk3(terminal ? ccol.x : thr.x * m0.x,                       // pixel * color (src/Lib.hs:79)
                   terminal ? ccol.y : thr.y * m0.y,
                   terminal ? ccol.z : thr.z * m0.z);
-        d = scatter(idx, e, din, bn);
+        d = scatter(idx, e, din, bn, hp);
         o = hp; last = idx; b = bn + 1;
     };
 
-    if (alive) d = scatter(cidx, ce, cd0, 0);
+    if (alive) d = scatter(cidx, ce, cd0, 0, cP0);
 
     // ---- phase 1: every lane on its own pixel --------------------------------
     const unsigned long long everyone = __ballot(true);
@@ -615,7 +653,7 @@ __global__ __launch_bounds__(NS == -2 ? 64 : TRACE_BLOCK) void trace_steal_kerne
 //   * sample index and bounce live in one counter (gs << 6 | bounce) that is
 //     also the Philox counter word and the loop's exit test.
 // ---------------------------------------------------------------------------
-template <int NS>
+template <int NS, bool SPH>
 __device__ __forceinline__ void closest_static(const StaticGeom<NS> &sg, f3 o, f3 v, int lastp, int &bestp,
                                                float &best_t)
 {
@@ -631,10 +669,14 @@ __device__ __forceinline__ void closest_static(const StaticGeom<NS> &sg, f3 o, f
         const float4 g0 = sg.g[k][0], g1 = sg.g[k][1], g2 = sg.g[k][2];
         const float on  = fmaf(o.z, g0.z, fmaf(o.y, g0.y, o.x * g0.x));
         const float den = fmaf(v.z, g1.z, fmaf(v.y, g1.y, v.x * g1.x));
-        const float t = fmaf(g0.w - on, __builtin_amdgcn_rcpf(den), -__builtin_bit_cast(float, 1u));
+        float t = fmaf(g0.w - on, __builtin_amdgcn_rcpf(den), -__builtin_bit_cast(float, 1u));
+        if constexpr (SPH) {
+            if (g1.w < 0.0f)                                       // wave-uniform: Sphere (extension)
+                t = fmaf(sphere_t(mk3(g2.x, g2.y, g2.z), -g1.w, o, v), 1.0f, -__builtin_bit_cast(float, 1u));
+        }
         const uint32_t key = __float_as_uint(t);
         bool ok = (key < best_key) & (16 * (k + 1) != lastp);     // 0 < t < best, not _lastStruck (src/Lib.hs:86-90)
-        if (g1.w != __builtin_inff()) {                            // wave-uniform: Disk (src/Object.hs:165-171)
+        if (g1.w != __builtin_inff() && !(SPH && g1.w < 0.0f)) {   // wave-uniform: Disk (src/Object.hs:165-171)
             const float dx = fmaf(t, v.x, o.x) - g2.x;
             const float dy = fmaf(t, v.y, o.y) - g2.y;
             const float dz = fmaf(t, v.z, o.z) - g2.z;
@@ -723,14 +765,20 @@ __global__ __launch_bounds__(STATIC_BLOCK) void trace_static_kernel(TraceArgs a,
     bool alive = traced;                                   // has a path in flight
     const PhiloxRegs pregs = philox_regs(a.seed);
 
-    auto scatter = [&](int idxp, float e, f3 din, uint32_t c1) -> f3 {
+    auto scatter = [&](int idxp, float e, f3 din, uint32_t c1, f3 at) -> f3 {
         uint32_t r0, r1;
         philox2x32_10_pre_v((uint32_t)(pre >> 32), (uint32_t)pre, c1, pregs, r0, r1);
         if constexpr (SPEC) {
-            if (e < -1.5f) {                               // _reflective (src/Lib.hs:110)
-                const float4 m3 = matp(idxp, 3);
-                return scatter_specular(din, mk3(m3.y, m3.z, m3.w), u_theta(r0), u_phi(r1), NOISE_REV);
+            const float4 m3 = matp(idxp, 3);
+            f3 nrm = mk3(m3.y, m3.z, m3.w);
+            const bool sphere = m3.x != m3.x;              // NaN marks the Sphere extension: normal at the hit point
+            if (sphere) {
+                const float4 m1 = matp(idxp, 1);
+                nrm = mk3((at.x - m1.x) * m1.w, (at.y - m1.y) * m1.w, (at.z - m1.z) * m1.w);
             }
+            if (e < -1.5f)                                 // _reflective (src/Lib.hs:110)
+                return scatter_specular(din, nrm, u_theta(r0), u_phi(r1), NOISE_REV);
+            if (sphere) return scatter_diffuse_about(nrm, r0, r1);
         }
         return scatter_diffuse_bits(matp(idxp, 1), matp(idxp, 2), matp(idxp, 3).x, r0, r1);   // src/Lib.hs:111
     };
@@ -738,7 +786,7 @@ __global__ __launch_bounds__(STATIC_BLOCK) void trace_static_kernel(TraceArgs a,
     // and returns in c1 the counter word (sample << 6 | 0) of a restarted path.
     auto trip = [&](auto all_alive, auto &&draw) {
         int kp; float t;
-        closest_static<NS>(sg, o, d, lastp, kp, t);
+        closest_static<NS, SPEC>(sg, o, d, lastp, kp, t);
         const bool live = decltype(all_alive)::value ? true : alive;
         if (!decltype(all_alive)::value) segs += live ? 1 : 0;            // phase 1 counts its trips wave-uniformly
         const float4 m0 = matp(kp, 0);
@@ -762,11 +810,11 @@ __global__ __launch_bounds__(STATIC_BLOCK) void trace_static_kernel(TraceArgs a,
         thr = mk3(terminal ? ccol.x : thr.x * m0.x,                       // pixel * color (src/Lib.hs:79)
                   terminal ? ccol.y : thr.y * m0.y,
                   terminal ? ccol.z : thr.z * m0.z);
-        d = scatter(idxp, e, din, c1);
+        d = scatter(idxp, e, din, c1, hp);
         o = hp; lastp = idxp; ctr = c1 + 1u;
     };
 
-    if (alive) d = scatter(cidxp, ce, cd0, ctr - 1u);
+    if (alive) d = scatter(cidxp, ce, cd0, ctr - 1u, cP0);
 
     // ---- phase 1: every lane on its own pixel --------------------------------
     const unsigned long long everyone = __ballot(true);
@@ -919,8 +967,17 @@ __global__ __launch_bounds__(256) void primary_kernel(TraceArgs a, int32_t *idx,
     if (idx) idx[pixel] = h.idx;
     if (t) t[pixel] = h.idx >= 0 ? h.t : 0.0;
     if (normal) {
-        for (int c = 0; c < 3; ++c)
-            normal[3 * (size_t)pixel + c] = h.idx >= 0 ? a.prim[(size_t)h.idx * PRIM_DOUBLES + 3 + c] : 0.0;
+        const double *p = h.idx >= 0 ? a.prim + (size_t)h.idx * PRIM_DOUBLES : nullptr;
+        const double dir[3] = {h.dx, h.dy, h.dz};
+        for (int c = 0; c < 3; ++c) {
+            double v = 0.0;
+            if (p) {
+                // getNormal (src/Object.hs:180-183); Sphere extension: (march - centre) / radius, as o_normal_at
+                if (p[10] == 2.0) { const double hit = 0.0 + h.t * dir[c]; v = (1.0 / p[9]) * (hit - p[c]); }
+                else v = p[3 + c];
+            }
+            normal[3 * (size_t)pixel + c] = v;
+        }
     }
 }
 

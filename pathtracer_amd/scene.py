@@ -34,7 +34,14 @@ class Disk:                     # src/Object.hs:52-54
     radius: float
 
 
-Form = Union[InfinitePlane, Disk]
+@dataclass
+class Sphere:                   # EXTENSION: the reference only has "TODO: add spheres" (src/Object.hs:191-194)
+    center: Vec
+    radius: float
+    normal: Vec = (0.0, 0.0, 0.0)       # unused: the normal is (point - center) / radius at the hit
+
+
+Form = Union[InfinitePlane, Disk, Sphere]
 
 
 @dataclass
@@ -50,6 +57,8 @@ class Object:                   # src/Object.hs:30-36
         f = self.form
         if isinstance(f, Disk):
             o.kind, pt, o.radius = _lib.PT_DISK, f.center, float(f.radius)
+        elif isinstance(f, Sphere):
+            o.kind, pt, o.radius = _lib.PT_SPHERE, f.center, float(f.radius)
         elif isinstance(f, InfinitePlane):
             o.kind, pt, o.radius = _lib.PT_INFINITE_PLANE, f.point, 0.0
         else:
@@ -79,6 +88,17 @@ infPlane3 = Object((1, 1, 0.1), 0, False, InfinitePlane((20, -20, 100), (-1, 0, 
 
 # objects = V.fromList [infPlane, infPlane2, infPlane3, light]  (src/Object.hs:147-148)
 objects = [infPlane, infPlane2, infPlane3, light]
+
+
+def random_sphere_scene(n: int, seed: int):
+    """BASELINE.json configs[3] as written ("random-sphere scene"): the generator
+    of random_disk_scene with every disk replaced by a sphere of the same centre
+    and radius.  Spheres are an extension with no reference counterpart
+    (SURVEY.md F4); include/pt.h (PT_SPHERE) states their definition."""
+    objs = random_disk_scene(n, seed)
+    return [o if isinstance(o.form, InfinitePlane) else
+            Object(o.color, o.emittance, o.reflective, Sphere(o.form.center, o.form.radius), o.name.replace("disk", "sphere"))
+            for o in objs]
 
 
 def random_disk_scene(n: int, seed: int):

@@ -48,6 +48,7 @@ def _load():
         "o_distance_from_prime": (C.c_int, [v, v, C.POINTER(OObject), C.POINTER(d)]),
         "o_distance_from": (C.c_int, [v, v, C.POINTER(OObject), C.POINTER(d)]),
         "o_march": (v, [v, v, d]),
+        "o_normal_at": (v, [C.POINTER(OObject), v]),
         "o_mk_stdgen": (StdGen, [C.c_int64]), "o_stdgen_next": (C.c_int32, [C.POINTER(StdGen)]),
         "o_stdgen_random_int": (C.c_int64, [C.POINTER(StdGen)]),
         "o_stdgen_random_double": (d, [C.POINTER(StdGen)]),
