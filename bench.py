@@ -82,6 +82,10 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--no-primary-reuse", action="store_true")
     ap.add_argument("--no-steal", action="store_true", help="PT_FLAG_NO_STEAL: strict per-lane sample order")
+    ap.add_argument("--scene", default="default",
+                    help="default | disks1000 | spheres1000 | disks10000 | spheres10000: the synthetic scenes of "
+                         "BASELINE.json configs[3]/[4] (SURVEY.md 8d generator); pass their --height/--width/--spp/--bounces")
+    ap.add_argument("--no-bvh", action="store_true", help="PT_FLAG_NO_BVH: linear scan over all objects")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="N > 1: all-reduce and output in line with the trace instead of overlapped with the next frame")
     args = ap.parse_args()
@@ -111,13 +115,23 @@ def main():
 
     my_spp, s_off, s_stride = shard_samples(args.spp, rank, world)
     P = pa.Params(args.height, args.width, args.camera_depth, args.spp, args.bounces)
-    flags = (pa.PT_FLAG_NO_PRIMARY_REUSE if args.no_primary_reuse else 0) | (pa.PT_FLAG_NO_STEAL if args.no_steal else 0)
+    flags = (pa.PT_FLAG_NO_PRIMARY_REUSE if args.no_primary_reuse else 0) | (pa.PT_FLAG_NO_STEAL if args.no_steal else 0) \
+        | (pa.PT_FLAG_NO_BVH if args.no_bvh else 0)
+    if args.scene == "default":
+        scene, scene_name = pa.objects, "reference default scene (4 objects)"
+    else:
+        kind, count = ("disks", args.scene[5:]) if args.scene.startswith("disks") else ("spheres", args.scene[7:])
+        n_obj = int(count)
+        gen = pa.random_disk_scene if kind == "disks" else pa.random_sphere_scene
+        scene = gen(n_obj, 1 if n_obj <= 1000 else 2)
+        scene_name = (f"synthetic {n_obj}-object random-{kind[:-1]} scene (SURVEY.md 8d generator, seed "
+                      f"{1 if n_obj <= 1000 else 2}" + ("; spheres are an extension without reference parity" if kind == "spheres" else "") + ")")
     # An explicit stream: libpt cannot be pointed at the legacy null stream, and
     # the all-reduce must be ordered after the trace kernel on the SAME stream.
     stream = torch.cuda.Stream()
     torch.cuda.set_stream(stream)
     pipelined = dist is not None and not args.no_pipeline
-    rs = [pa.Renderer(P, pa.objects, seed=0, device=local_rank, sample_offset=s_off, sample_stride=s_stride,
+    rs = [pa.Renderer(P, scene, seed=0, device=local_rank, sample_offset=s_off, sample_stride=s_stride,
                       flags=flags) for _ in range(2 if pipelined else 1)]
     for q in rs:
         q.set_stream(stream.cuda_stream)      # kernels, all-reduce and events share this stream
@@ -181,7 +195,11 @@ def main():
 
     if rank == 0:
         value = total_segs_step * args.steps / elapsed / 1e6
-        F = flops_per_segment(pa.objects)
+        # algorithmic flops: SURVEY 8(d)'s per-segment figure for a scene searched by the linear scan; a
+        # scene searched through the spatial index executes far fewer object tests than that formula
+        # counts, so no roofline fraction is claimed for it
+        indexed = len(scene) > 8 and not args.no_bvh
+        F = flops_per_segment(scene)
         segs_launch_rank0 = r.segments / max(launches, 1)
         achieved = F * segs_launch_rank0 / (kern_ms * 1e-3) / 1e12
         traffic = None
@@ -200,7 +218,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"reference default scene (4 objects), Params.height={args.height} "
+            "config": {"workload": f"{scene_name}, Params.height={args.height} "
                                    f"Params.width={args.width} ({args.height}x{args.width} px image), "
                                    f"{args.spp} spp, maxBounces {args.bounces}, cameraDepth {args.camera_depth:g}; "
                                    f"sample-split over {world} GPU(s) + one RCCL all-reduce + RGB8 output",
@@ -213,13 +231,20 @@ def main():
             "roofline": {"bound": "valu", "achieved": round(achieved, 3), "peak": FP32_VALU_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / FP32_VALU_PEAK_TFLOPS, 4),
                          "traffic": traffic,
-                         "kernel": "trace_kernel" if (args.no_steal or args.no_primary_reuse) else "trace_static_kernel",
+                         "kernel": "trace_kernel" if (args.no_steal or args.no_primary_reuse) else
+                                   ("trace_static_kernel" if len(scene) <= 8 else "trace_steal_kernel"),
                          "kernel_ms": round(kern_ms, 4),
                          "flops_per_segment": F, "segments_per_launch": int(segs_launch_rank0),
                          "note": "fp32 VALU-bound path (no MFMA, ~0 HBM bytes per segment); peak = fp32 vector "
                                  "157.3 TFLOP/s (= the fp32 MFMA peak)"},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if indexed:
+            out["roofline"].update(achieved=None, frac=None, traffic=None,
+                                   note="searched through the BVH: the linear-scan flop formula does not apply; "
+                                        "see value (Mrays/s) and DESIGN.md 3.4")
+        if args.scene != "default":
+            out["metric"] = "Mrays/s (samples x bounces)"
+        if world == 1 and not args.no_cpu_baseline and args.scene == "default":
             threads = args.cpu_threads or int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
             out["cpu_baseline"] = cpu_baseline(args.height, args.width, args.camera_depth, args.bounces, threads)
         print(json.dumps(out), flush=True)
