@@ -366,7 +366,7 @@ int pt_trace(pt_ctx *c, int32_t iters)
     if (iters < 0) return fail(c, PT_ERR_INVALID, "pt_trace: iters < 0");
     const int64_t last_global =
         (int64_t)c->p.sample_offset + (c->samples_done + iters) * (int64_t)c->p.sample_stride;
-    if (last_global > MAX_GLOBAL_SAMPLES)
+    if (last_global >= MAX_GLOBAL_SAMPLES)       // the kernels shift (first index beyond the launch) << 6 in 32 bits
         return fail(c, PT_ERR_LIMIT, "pt_trace: global sample index would exceed 2^26");
 
     const bool reuse = !(c->p.flags & PT_FLAG_NO_PRIMARY_REUSE);

@@ -393,6 +393,28 @@ def test_error_behaviour(pa):
             r.upload([])
 
 
+def test_sample_index_limit_and_the_last_usable_samples(pa):
+    """The global sample index shares a Philox word with the 6-bit bounce: indices
+    below 2^26.  The last usable samples must render exactly what the oracle does
+    with the same indices (the kernels shift the index left by 6 in 32 bits), and
+    one sample more must be refused with PT_ERR_LIMIT."""
+    H, W, B = 24, 40, 6
+    top = (1 << 26) - 1                                    # first index beyond a launch must stay below 2^26
+    zero = np.zeros((H, W, 3), np.float32)
+    for flags in (0, 4):
+        with pa.Renderer(pa.Params(H, W, 500.0, 1, B), seed=2, flags=flags) as r:
+            r.write_sum_f32(zero, samples_done=top - 5)
+            r.trace(5)
+            dev = r.read_sum()
+            with pytest.raises(pa.PtError) as e:
+                r.trace(1)
+            assert e.value.status == -5
+        px = np.arange(H * W, dtype=np.int32)
+        ora, _ = O.trace_pixels(O.params(H, W, 500.0, B, O.PHILOX, 2), O.default_scene(), px, 5, s_begin=top - 5)
+        assert _mismatch_fraction(dev, ora.reshape(H, W, 3)) <= 0.01
+        assert ora.sum() > 0
+
+
 # ----------------------------------------------------- committed fixtures ----
 def test_against_committed_golden_fixtures(pa):
     """tests/golden/*.npz (written by make_golden.py from the oracle, cross-checked
