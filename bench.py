@@ -9,10 +9,11 @@ resident in HBM:
     indices) -> [N > 1: ONE RCCL all-reduce (sum) of the fp32 canvas over xGMI]
     -> fused RGB8 output kernel on rank 0.
 The total work per step is fixed as N grows, so "scaling" is "strong".
-For N > 1 the frames are double-buffered (pathtracer_amd.distributed.
-PipelinedFrames): frame k's all-reduce and output run on their own streams
-while frame k+1 is traced into the other canvas; the timed region ends with a
-full drain, so all K frames are complete (traced, reduced, quantised) in it.
+Frames are double-buffered (pathtracer_amd.distributed.PipelinedFrames), for
+every N alike: frame k's all-reduce and output run on their own streams while
+frame k+1 is traced into the other canvas on a second trace stream; the timed
+region ends with a full drain, so all K frames are complete (traced, reduced,
+quantised) in it.  --no-pipeline runs the steps strictly in line.
 
 value = closest-hit searches executed by all ranks in the timed steps / wall
 time (Mrays/s, a ray = one closestObjectTo, src/Lib.hs:81).  The searches are
@@ -87,7 +88,7 @@ def main():
                          "BASELINE.json configs[3]/[4] (SURVEY.md 8d generator); pass their --height/--width/--spp/--bounces")
     ap.add_argument("--no-bvh", action="store_true", help="PT_FLAG_NO_BVH: linear scan over all objects")
     ap.add_argument("--no-pipeline", action="store_true",
-                    help="N > 1: all-reduce and output in line with the trace instead of overlapped with the next frame")
+                    help="trace, all-reduce and output strictly in line instead of overlapped with the next frame")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -130,7 +131,7 @@ def main():
     # the all-reduce must be ordered after the trace kernel on the SAME stream.
     stream = torch.cuda.Stream()
     torch.cuda.set_stream(stream)
-    pipelined = dist is not None and not args.no_pipeline
+    pipelined = not args.no_pipeline         # the same frame loop for every N; N = 1 simply has no all-reduce
     rs = [pa.Renderer(P, scene, seed=0, device=local_rank, sample_offset=s_off, sample_stride=s_stride,
                       flags=flags) for _ in range(2 if pipelined else 1)]
     for q in rs:

@@ -48,7 +48,9 @@ class PipelinedFrames:
     (the pull-next-frame contract of app/Web.hs:42-65): frame k is traced into
     canvas k % 2 while frame k-1's all-reduce (RCCL's own stream) and RGB8
     output (a side stream) are still in flight, so the collective's time is
-    hidden behind the next frame's kernel instead of added to it.  Every frame
+    hidden behind the next frame's kernel instead of added to it, and the two
+    frames' trace kernels run on two streams so that one's tail overlaps the
+    other's head.  Every frame
     is still one pt_reset + pt_trace + ONE all-reduce + the output kernel; only
     their placement on streams changes.  `drain()` waits for everything.
 
@@ -62,33 +64,36 @@ class PipelinedFrames:
         self.torch = torch
         self.r, self.cv, self.rgb = renderers, canvases, rgb
         self.rank, self.spp_total, self.my_spp, self.mode, self.dist = rank, spp_total, my_spp, mode, dist
-        self.main = torch.cuda.current_stream()
-        if self.main.cuda_stream == 0:
+        if torch.cuda.current_stream().cuda_stream == 0:
             raise ValueError("PipelinedFrames needs an explicit torch stream as the current stream: libpt cannot "
                              "be pointed at the legacy null stream (pt_set_stream(NULL) = the context's own stream)")
+        # One trace stream per canvas: frames k and k+1 are independent, so the head of
+        # frame k+1's kernel fills the CUs that the tail of frame k's kernel leaves idle.
+        self.mains = [torch.cuda.current_stream(), torch.cuda.Stream()]
         self.side = torch.cuda.Stream()
-        for r in renderers:
-            r.set_stream(self.main.cuda_stream)
+        for r, m in zip(renderers, self.mains):
+            r.set_stream(m.cuda_stream)
         self.done = [None, None]          # event: canvas k % 2 is free again
         self.k = 0
 
     def step(self):
         torch = self.torch
         b = self.k & 1
-        r, cv = self.r[b], self.cv[b]
-        if self.done[b] is not None:
-            self.main.wait_event(self.done[b])           # frame k-2's output has left this canvas
-        r.reset()
-        r.trace(self.my_spp)
-        work = None
-        if self.dist is not None:
-            work = self.dist.all_reduce(cv, op=self.dist.ReduceOp.SUM, async_op=True)   # ordered after the trace
-        traced = torch.cuda.Event()
-        traced.record(self.main)
+        r, cv, main = self.r[b], self.cv[b], self.mains[b]
+        with torch.cuda.stream(main):
+            if self.done[b] is not None:
+                main.wait_event(self.done[b])                # frame k-2's output has left this canvas
+            r.reset()
+            r.trace(self.my_spp)
+            work = None
+            if self.dist is not None:                        # RCCL's stream is ordered after `main` at this call
+                work = self.dist.all_reduce(cv, op=self.dist.ReduceOp.SUM, async_op=True)
+            traced = torch.cuda.Event()
+            traced.record(main)
         with torch.cuda.stream(self.side):
             self.side.wait_event(traced)
             if work is not None:
-                work.wait()                               # the side stream waits for the collective
+                work.wait()                                   # the side stream waits for the collective
             if self.rank == 0:
                 r.rgb8_device_on(self.rgb[b].data_ptr(), self.side.cuda_stream, self.mode, self.spp_total)
             ev = torch.cuda.Event()
@@ -99,4 +104,5 @@ class PipelinedFrames:
 
     def drain(self):
         self.side.synchronize()
-        self.main.synchronize()
+        for m in self.mains:
+            m.synchronize()
