@@ -33,7 +33,7 @@ struct BvhNode {
 };
 static_assert(sizeof(BvhNode) == 32, "two float4 per node");
 
-constexpr int BVH_LEAF_MAX = 4;
+constexpr int BVH_LEAF_MAX = 8;
 constexpr int BVH_SAH_DEPTH = 14;       // surface-area splits down to here, balanced median splits below:
 constexpr int BVH_MAX_DEPTH = 30;       //   14 + ceil(log2(65536 / 4)) = 28 levels at most
 constexpr int BVH_STACK = 32;           // per-lane stack entries on the device (> BVH_MAX_DEPTH)

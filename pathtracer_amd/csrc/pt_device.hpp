@@ -372,7 +372,7 @@ __device__ __forceinline__ bool slab_hit(float4 n0, float4 n1, float ox, float o
 }
 
 constexpr int BVH_STACK_ENTRIES = 32;
-constexpr int BVH_LEAF_SLOTS = 4;         // = BVH_LEAF_MAX of pt_bvh.hpp    // = BVH_STACK of pt_bvh.hpp (tree depth <= 30)
+constexpr int BVH_LEAF_SLOTS = 8;         // = BVH_LEAF_MAX of pt_bvh.hpp
 
 // Near-child-first walk.  `stack` is this lane's column of an LDS array laid out
 // [entry][lane] (stride = lanes per workgroup): conflict-free, no scratch memory.
