@@ -73,6 +73,19 @@ class Renderer:
         assert a.shape == self.shape
         check(lib.pt_write_sum_f32(self._ctx, a.ctypes.data_as(C.c_void_p), samples_done), self._ctx)
 
+    # Checkpoint / resume.  The reference's resumable state is the
+    # per-pixel pair (Vec3 sum, StdGen) threaded by `iterate` (src/Lib.hs:56-65); with a
+    # counter-based generator it is just (radiance sums, samples done).
+    def checkpoint(self) -> dict:
+        return {"sum": self.read_sum_f32(), "samples_done": self.samples_done,
+                "params": (self.params.height, self.params.width, self.params.cameraDepth, self.params.maxBounces)}
+
+    def restore(self, state: dict):
+        want = (self.params.height, self.params.width, self.params.cameraDepth, self.params.maxBounces)
+        if tuple(state["params"]) != want:
+            raise ValueError(f"checkpoint was taken with Params {tuple(state['params'])}, this renderer has {want}")
+        self.write_sum_f32(state["sum"], int(state["samples_done"]))
+
     def read_rgb8(self, mode: int = _lib.PT_RGB8_REFERENCE) -> np.ndarray:
         """repa3ToImage: array (W, H, 3) uint8 = rows of an image H wide, W tall."""
         out = np.empty((self.params.width, self.params.height, 3), dtype=np.uint8)

@@ -374,6 +374,37 @@ def test_rgb8_ragged_tiles(pa, H, W):
     assert np.array_equal(dev, O.repa3_to_image(O.params(H, W, 500.0, 4), canvas.astype(np.float64)))
 
 
+@pytest.mark.parametrize("flags", [0, 4])
+def test_checkpoint_resume_continues_the_same_render(pa, flags):
+    """(sums, samples done) is the whole resumable state: a render resumed in a
+    NEW context continues with the same global sample indices, so under
+    PT_FLAG_NO_STEAL it equals the uninterrupted render bit for bit, and up to
+    fp32 summation order otherwise."""
+    P = pa.Params(48, 72, 500.0, 12, 8)
+    with pa.Renderer(P, seed=6, flags=flags) as whole:
+        whole.trace(12)
+        want, want_segs = whole.read_sum_f32(), whole.segments
+    with pa.Renderer(P, seed=6, flags=flags) as first:
+        first.trace(5)
+        state = first.checkpoint()
+        segs_a = first.segments
+    assert state["samples_done"] == 5
+    with pa.Renderer(P, seed=6, flags=flags) as second:
+        second.restore(state)
+        second.trace(7)
+        got = second.read_sum_f32()
+        assert second.samples_done == 12
+        segs_b = second.segments
+    if flags & 4:
+        assert np.array_equal(got, want)
+    else:
+        assert np.allclose(got, want, rtol=4e-6, atol=1e-6)
+    assert segs_a + segs_b == want_segs + 48 * 72          # the resumed launch recomputed the primary hits
+    with pa.Renderer(pa.Params(48, 72, 500.0, 12, 7), seed=6) as other:
+        with pytest.raises(ValueError):
+            other.restore(state)
+
+
 # -------------------------------------------------------------- errors -------
 def test_error_behaviour(pa):
     with pytest.raises(pa.PtError) as e:
