@@ -8,30 +8,63 @@
 // with the SAME arithmetic as the linear scan, and ties are broken by object
 // index as Data.Vector.minimumBy does, so the winner is the linear scan's winner.
 //
-// Layout: binary BVH in depth-first order, one 32-byte node per box.  A lane
+// Layout: binary BVH in depth-first order, one 16-byte node per box.  A lane
 // walks it near child first (by the sign of the ray direction along the node's
 // split axis) with a short per-lane stack of far children in LDS; every node is
-// one 32-byte gather from L2.  Depth is bounded (BVH_MAX_DEPTH) so the stack
+// one 16-byte gather from L2.  Depth is bounded (BVH_MAX_DEPTH) so the stack
 // cannot overflow whatever the scene.
 #pragma once
 
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstring>
 #include <limits>
 #include <vector>
 
 namespace pt {
 
-// 32 bytes: lo.xyz, skip | hi.xyz, leaf
-//   skip: index of the first node after this subtree (depth-first order)
-//   leaf: >= 0: first_prim << 3 | (count - 1)
-//         <  0: inner node, -(code + 1) with code = right_child << 2 | split_axis; left child = this + 1
+// 16 bytes per node = ONE 16-byte gather per step of the walk (the walk is bound
+// by the CU's divergent-gather rate): the box as six binary16
+// values rounded OUTWARD, plus one code word.
+//   h[0..2] = lo.xyz, h[3..5] = hi.xyz   (a coordinate beyond binary16's range becomes +-Inf: still conservative)
+//   code >= 0: leaf, first_prim << 3 | (count - 1)
+//   code <  0: inner node, -(c + 1) with c = right_child << 2 | split_axis; left child = this + 1
 struct BvhNode {
-    float lo[3]; int32_t skip;
-    float hi[3]; int32_t leaf;
+    uint16_t h[6];
+    int32_t code;
 };
-static_assert(sizeof(BvhNode) == 32, "two float4 per node");
+static_assert(sizeof(BvhNode) == 16, "one float4 per node");
+
+// binary16 bits of the largest half <= x (up = false) or the smallest half >= x (up = true)
+inline uint16_t half_round_dir(float x, bool up)
+{
+    if (x != x) return up ? 0x7c00 : 0xfc00;                 // NaN bound: open the box
+    const bool neg = std::signbit(x);
+    const float ax = std::fabs(x);
+    uint32_t mag;                                             // magnitude rounded toward zero ...
+    bool exact;
+    if (ax == std::numeric_limits<float>::infinity()) { mag = 0x7c00; exact = true; }
+    else if (ax > 65504.0f) { mag = 0x7bff; exact = false; }  // beyond the largest finite half
+    else if (ax < 6.103515625e-05f) {                         // subnormal half: units of 2^-24
+        const float q = ax * 16777216.0f;
+        mag = (uint32_t)q; exact = (float)mag == q;
+    } else {
+        uint32_t au; std::memcpy(&au, &ax, 4);
+        const uint32_t e = (au >> 23) - 112, m = au & 0x7fffffu;
+        mag = (e << 10) | (m >> 13); exact = (m & 0x1fffu) == 0;
+    }
+    if (!exact && up != neg) mag += 1;                        // ... then away from zero where the direction asks (0x7bff + 1 = Inf)
+    return (uint16_t)((neg ? 0x8000u : 0u) | mag);
+}
+
+inline float half_bits_to_float(uint16_t h)
+{
+    const uint32_t e = (h >> 10) & 31, m = h & 1023;
+    float v = e == 0 ? std::ldexp((float)m, -24) : e == 31 ? (m ? std::nanf("") : std::numeric_limits<float>::infinity())
+                                                          : std::ldexp((float)(m | 1024), (int)e - 25);
+    return (h & 0x8000) ? -v : v;
+}
 
 constexpr int BVH_LEAF_MAX = 8;
 constexpr int BVH_SAH_DEPTH = 14;       // surface-area splits down to here, balanced median splits below:
@@ -69,8 +102,6 @@ public:
         prim_base_ = prim_base;
         out_ = &out;
         emit(0, (int)order_.size(), 0);
-        // skip links: a node's subtree occupies [i, end_i); its skip is end_i
-        for (size_t i = 0; i < out.nodes.size(); ++i) out.nodes[i].skip = end_[i];
         for (int32_t id : order_) out.prims.push_back(id);
     }
 
@@ -109,19 +140,18 @@ private:
         const BvhBox bb = bounds(b, e);
         BvhNode n;
         for (int a = 0; a < 3; ++a) {
-            // round outward to fp32, then pad: the device's slab test is plain fp32
-            n.lo[a] = std::nextafter((float)(bb.lo[a] - pad_), -std::numeric_limits<float>::infinity());
-            n.hi[a] = std::nextafter((float)(bb.hi[a] + pad_), std::numeric_limits<float>::infinity());
+            // pad, then round outward to binary16: the device's slab test is plain fp32 on these values
+            n.h[a]     = half_round_dir((float)(bb.lo[a] - pad_) - std::fabs((float)(bb.lo[a] - pad_)) * 1e-7f, false);
+            n.h[3 + a] = half_round_dir((float)(bb.hi[a] + pad_) + std::fabs((float)(bb.hi[a] + pad_)) * 1e-7f, true);
         }
-        n.skip = 0;
         const int cnt = e - b;
         if (cnt <= BVH_LEAF_MAX) {
-            n.leaf = ((prim_base_ + b) << 3) | (cnt - 1);
+            n.code = ((prim_base_ + b) << 3) | (cnt - 1);
             out_->nodes[me] = n;
             end_[me] = (int32_t)out_->nodes.size();
             return;
         }
-        n.leaf = -1;
+        n.code = -1;
         out_->nodes[me] = n;
         // binned SAH over the centroids of the widest axes; median split as the fallback
         int best_axis = -1, best_split = -1;
@@ -184,7 +214,7 @@ private:
         emit(b, mid, depth + 1);                       // the low side of `axis` first
         const int32_t right = (int32_t)out_->nodes.size();
         emit(mid, e, depth + 1);
-        out_->nodes[me].leaf = -(((right << 2) | axis) + 1);
+        out_->nodes[me].code = -(((right << 2) | axis) + 1);
         end_[me] = (int32_t)out_->nodes.size();
         if (depth + 1 > max_depth) max_depth = depth + 1;
     }

@@ -360,18 +360,21 @@ __device__ inline PrimaryHit primary_hit_f64(const double *__restrict__ prim, in
 // runs the arithmetic of the linear scan, and an equal t keeps the lower object
 // index, so the result is the scan's.  The slab test is fp32 on boxes the host
 // rounded outward and padded.
-__device__ __forceinline__ bool slab_hit(float4 n0, float4 n1, float ox, float oy, float oz,
+// node = (lo.xy | lo.z hi.x | hi.yz as binary16 pairs, code): pt_bvh.hpp
+__device__ __forceinline__ bool slab_hit(float4 nd, float ox, float oy, float oz,
                                          float ix, float iy, float iz, float t_best)
 {
-    const float ax = (n0.x - ox) * ix, bx = (n1.x - ox) * ix;
-    const float ay = (n0.y - oy) * iy, by = (n1.y - oy) * iy;
-    const float az = (n0.z - oz) * iz, bz = (n1.z - oz) * iz;
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    const h2 a = __builtin_bit_cast(h2, nd.x), b = __builtin_bit_cast(h2, nd.y), c = __builtin_bit_cast(h2, nd.z);
+    const float lox = (float)a.x, loy = (float)a.y, loz = (float)b.x, hix = (float)b.y, hiy = (float)c.x, hiz = (float)c.y;
+    const float ax = (lox - ox) * ix, bx = (hix - ox) * ix;
+    const float ay = (loy - oy) * iy, by = (hiy - oy) * iy;
+    const float az = (loz - oz) * iz, bz = (hiz - oz) * iz;
     const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
     const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), t_best));
     return tn <= tf;
 }
 
-constexpr int BVH_STACK_ENTRIES = 32;
 constexpr int BVH_LEAF_SLOTS = 8;         // = BVH_LEAF_MAX of pt_bvh.hpp
 
 // Near-child-first walk.  `stack` is this lane's column of an LDS array laid out
@@ -399,9 +402,9 @@ __device__ __forceinline__ void bvh_walk(const float4 *__restrict__ nodes,
     for (;;) {
         int code = -1;
         while (n >= 0) {
-            const float4 n0 = nodes[2 * n], n1 = nodes[2 * n + 1];
-            if (!slab_hit(n0, n1, ox, oy, oz, ix, iy, iz, t_best())) { n = pop(); continue; }
-            const int c = __float_as_int(n1.w);
+            const float4 nd = nodes[n];
+            if (!slab_hit(nd, ox, oy, oz, ix, iy, iz, t_best())) { n = pop(); continue; }
+            const int c = __float_as_int(nd.w);
             if (c >= 0) { code = c; break; }
             const int cc = -(c + 1), right = cc >> 2, left = n + 1;
             const bool right_first = (neg >> (cc & 3)) & 1u;

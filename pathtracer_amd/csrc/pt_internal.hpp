@@ -39,7 +39,7 @@ struct TraceArgs {
     int      fresh;                    // 1: the canvas is logically zero, start the sums at 0 without reading it
     int      tile_objs;                // objects per LDS tile (tiled kernel; set by the launcher)
     // spatial index over the finite forms (pt_bvh.hpp); n_nodes == 0: none, linear scan
-    const float4  *bvh_nodes;          // 2 float4 per node: (lo.xyz, skip) (hi.xyz, leaf)
+    const float4  *bvh_nodes;          // 1 float4 per node: six binary16 box bounds + code (pt_bvh.hpp)
     const int32_t *bvh_prims;          // [unbounded objects..., finite objects in leaf order...]
     const float4  *bvh_geom;           // geometry records in bvh_prims order (3 float4 each, object index in [2].w), padded
     int      n_nodes;
