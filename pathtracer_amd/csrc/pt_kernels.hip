@@ -1,27 +1,33 @@
 // pt_kernels.hip -- gfx950 kernels of the radiance loop.
 //
-//   trace_kernel   : Lib.traceCanvas / terminalColor / closestObjectTo /
-//                    bounceRay (src/Lib.hs:58-132) for n samples per pixel.
-//   primary_kernel : fp64 primary segment, the geometry parity hook.
-//   rgb8_kernel    : Conversion.repa3ToImage + listToPixelRGB8
-//                    (src/Conversion.hs:17-28), transposing through LDS.
-//   dev_* kernels  : device-function parity hooks.
+//   trace_static_kernel : Lib.traceCanvas / terminalColor / closestObjectTo /
+//                         bounceRay (src/Lib.hs:58-132) for n samples per pixel,
+//                         scenes of <= 8 objects (object list in the kernel
+//                         arguments): THE hot kernel, the one bench.py times.
+//   trace_steal_kernel  : the same loop for larger scenes, over the scalar-
+//                         streamed object list (NS = 0) or the BVH (NS = -2).
+//   trace_kernel        : the strict variant (PT_FLAG_NO_STEAL /
+//                         NO_PRIMARY_REUSE / LDS_TILES): a pixel's samples are
+//                         summed strictly in order by its own lane.
+//   primary_kernel      : fp64 primary segment, the geometry parity hook.
+//   rgb8_kernel         : Conversion.repa3ToImage + listToPixelRGB8
+//                         (src/Conversion.hs:17-28), transposing through LDS.
+//   dev_* kernels       : device-function parity hooks.
 //
-// Execution model of trace_kernel (one lane = one pixel, a wave = 64 adjacent
-// pixels of a canvas row):
+// Execution model of the trace kernels (one lane = one pixel, a wave = 64
+// adjacent pixels of a canvas row):
 //   every lane runs a SEGMENT state machine -- one closest-hit search plus one
 //   scatter per loop trip -- and a lane whose path ends (miss, light, depth
 //   cap) starts its pixel's next sample in the same trip.  All 64 lanes
 //   therefore execute the same instruction stream on every trip no matter how
-//   long their individual paths are; the only idle lanes are those that have
-//   finished their whole sample quota (the tail).  Path depth divergence,
-//   which would otherwise leave a wave running at the pace of its longest
-//   path, never reaches the exec mask.
+//   long their individual paths are.  Path depth divergence, which would
+//   otherwise leave a wave running at the pace of its longest path, never
+//   reaches the exec mask; lanes that run out of samples help the other pixels
+//   of their wave (work sharing, see trace_steal_kernel).
 //   The object list is indexed wave-uniformly, so for small scenes it rides
-//   in SGPRs (kernel-argument segment); materials are per-lane gathers from
-//   an LDS copy staged once per workgroup.
+//   in SGPRs / wave-uniform VGPRs; materials are per-lane gathers from an LDS
+//   copy staged once per workgroup.
 #include "pt_internal.hpp"
-
 
 #include <type_traits>
 
