@@ -8,7 +8,9 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline"
+# --no-pipeline: launches strictly one after the other, so that a kernel's duration in the trace is its own
+# (the default frame loop overlaps the tail of one frame's kernel with the head of the next)
+BENCH="python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-pipeline"
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/trace.log 2>&1 || exit 1
 i=0
 for C in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY" \

@@ -13,7 +13,7 @@ tag = sys.argv[1]
 kern = sys.argv[2] if len(sys.argv) > 2 else "trace_static_kernel<4, false>"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", tag)
-lines = [f"# {tag}: rocprofv3 PMC passes over `python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline` (profiles/run_pmc.sh {tag})",
+lines = [f"# {tag}: rocprofv3 PMC passes over `python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-pipeline` (profiles/run_pmc.sh {tag})",
          f"# per-launch means over the dispatches of {kern}; default scene 1920x1080, 1024 spp, maxBounces 8"]
 C = {}
 for p in sorted(glob.glob(os.path.join(src, "pmc*"))):
