@@ -51,7 +51,7 @@ instance Storable PtParams where
 newtype PtObject = PtObject Object
 
 instance Storable PtObject where
-  sizeOf _ = 96
+  sizeOf _ = 112
   alignment _ = 8
   peek _ = error "PtObject: write-only"
   poke p (PtObject (Object (Color (Triple r g b)) emit refl form _name)) = do
@@ -65,6 +65,7 @@ instance Storable PtObject where
     pokeByteOff p 56 (radius :: Double)
     mapM_ (\(k, x) -> pokeByteOff p (64 + 8 * k) (x :: Double)) (zip [0 ..] [r, g, b])
     pokeByteOff p 88 (emit :: Double)
+    pokeByteOff p 96 (0 :: Double); pokeByteOff p 104 (0 :: Double)   -- extent: PT_RECTANGLE only (Object.hs:57-61 is commented out)
 
 -- `safe`: a call lasts milliseconds to seconds and `web` runs -threaded
 -- (pathtracer.cabal:37); Warp's other threads must keep running meanwhile.

@@ -39,14 +39,19 @@ struct Params {
     int maxBounces = Params_defaults::maxBounces;
 };
 
-struct Form {                                           // src/Object.hs:51-56
-    enum Kind { InfinitePlane = PT_INFINITE_PLANE, Disk = PT_DISK, Sphere = PT_SPHERE /* extension, src/Object.hs:191-194 is a TODO */ } kind;
+struct Form {                                           // src/Object.hs:51-61
+    enum Kind { InfinitePlane = PT_INFINITE_PLANE, Disk = PT_DISK,
+                Sphere = PT_SPHERE,        // extension, src/Object.hs:191-194 is a TODO
+                Rectangle = PT_RECTANGLE   // extension, src/Object.hs:57-61 is commented out (include/pt.h defines it)
+    } kind;
     Triple point;      // _point | _center
     Triple normal;     // _normal
     double radius;     // _radius (Disk)
+    double height = 0.0, width = 0.0;   // _height, _width (Rectangle)
     static Form infinitePlane(Triple p, Triple n) { return Form{InfinitePlane, p, n, 0.0}; }
     static Form disk(Triple c, Triple n, double r) { return Form{Disk, c, n, r}; }
     static Form sphere(Triple c, double r) { return Form{Sphere, c, Triple{0, 0, 0}, r}; }
+    static Form rectangle(Triple c, Triple n, double height, double width) { return Form{Rectangle, c, n, 0.0, height, width}; }
 };
 
 struct Object {                                         // src/Object.hs:30-36
@@ -66,6 +71,7 @@ struct Object {                                         // src/Object.hs:30-36
         o.radius = form.radius;
         o.color[0] = color.x; o.color[1] = color.y; o.color[2] = color.z;
         o.emittance = emittance;
+        o.extent[0] = form.height; o.extent[1] = form.width;
         return o;
     }
 };

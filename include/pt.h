@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PT_ABI_VERSION 1
+#define PT_ABI_VERSION 2   /* 2: pt_object gained extent[2] (PT_RECTANGLE) */
 
 typedef enum {
     PT_OK             =  0,
@@ -49,21 +49,37 @@ typedef enum {
  *     h = sqrt((r^2 - l.l)/(v.v));   t = -m - h if that is positive, else -m + h;
  * then distanceFrom's guard 0 < t < Inf (src/Object.hs:159).  The normal at a
  * hit point p is (p - c)/r, outward, never flipped toward the ray (as for the
- * reference's forms); diffuse and specular scatter use it as they use _normal. */
-enum { PT_INFINITE_PLANE = 0, PT_DISK = 1, PT_SPHERE = 2 };
+ * reference's forms); diffuse and specular scatter use it as they use _normal.
+ *
+ * PT_RECTANGLE is an EXTENSION too: the reference carries it as a commented-out
+ * constructor { _center, _normal, _height, _width } with an unfinished guard
+ * (src/Object.hs:57-61, :172-175) and never says how the sides are oriented, so
+ * this comment is its definition.  point = centre c, normal = _normal (raw, any
+ * length), extent = { _height, _width }.  The distance is the guarded plane
+ * distance through c, exactly as for a Disk (src/Object.hs:166-167); with
+ * (theta', phi') = toSphericalCoords _normal (src/Util.hs:114-122), the sides run
+ * along the images of the local x and y axes under the rotation rotateRel uses
+ * for this normal (src/Util.hs:131-145):
+ *     u = rotateAbs (1,0,0) theta' phi',   w = rotateAbs (0,1,0) theta' phi',
+ * and the hit point p = march ray t (src/Object.hs:151-153) is inside when
+ *     |(p - c).u| < _width / 2   and   |(p - c).w| < _height / 2
+ * (strict, like the Disk's distanceFromCenter < radius).  A non-positive or NaN
+ * side is never hit.  Scatter uses _normal as for a Disk. */
+enum { PT_INFINITE_PLANE = 0, PT_DISK = 1, PT_SPHERE = 2, PT_RECTANGLE = 3 };
 
 /* One Object with its Form flattened (src/Object.hs:30-36, :51-56).  Doubles,
  * as the Haskell records hold; the library converts to its fp32 SoA layout at
  * upload.  _name is not carried: the reference uses it only inside Eq Object
  * (src/Object.hs:38-40), which the device replaces by index identity. */
 typedef struct {
-    int32_t kind;          /* PT_INFINITE_PLANE | PT_DISK | PT_SPHERE (extension: point = centre, radius; normal unused) */
+    int32_t kind;          /* PT_INFINITE_PLANE | PT_DISK | PT_SPHERE | PT_RECTANGLE (the last two: extensions, see above) */
     int32_t reflective;    /* _reflective  (src/Object.hs:33)                  */
     double  point[3];      /* _point / _center (src/Object.hs:52,55)           */
     double  normal[3];     /* _normal, raw, not normalised (src/Object.hs:53,56) */
     double  radius;        /* _radius, Disk only (src/Object.hs:54)            */
     double  color[3];      /* _color       (src/Object.hs:31)                  */
     double  emittance;     /* _emittance   (src/Object.hs:32)                  */
+    double  extent[2];     /* PT_RECTANGLE only: { _height, _width } (src/Object.hs:60-61); else ignored */
 } pt_object;
 
 /* Params.hs made a run-time value (src/Params.hs:3-11; numIters is the

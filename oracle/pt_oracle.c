@@ -194,6 +194,21 @@ static int plane_prime(o_vec3 origin, o_vec3 vector, o_vec3 point, o_vec3 normal
 /* guard (0 < distance && distance < 1/0)  (src/Object.hs:159) */
 static int guard_t(double t) { return (0.0 < t) && (t < INFINITY); }
 
+/* EXTENSION (O_RECTANGLE).  The reference never says how a Rectangle's sides are
+ * oriented (src/Object.hs:57-61 has only _center, _normal, _height, _width), so
+ * this is the definition: they run along the images of the local x and y axes
+ * under the rotation rotateRel applies for this normal (src/Util.hs:140-145),
+ *   u = rotateAbs (1,0,0) theta' phi',  w = rotateAbs (0,1,0) theta' phi',
+ * with (theta', phi') = toSphericalCoords normal. */
+void o_rectangle_axes(const o_object *f, o_vec3 *u, o_vec3 *w)
+{
+    double t2, p2;
+    o_to_spherical(v3(f->normal), &t2, &p2);
+    o_vec3 ex = { 1.0, 0.0, 0.0 }, ey = { 0.0, 1.0, 0.0 };
+    *u = o_rotate_abs(ex, t2, p2);
+    *w = o_rotate_abs(ey, t2, p2);
+}
+
 int o_distance_from_prime(o_vec3 origin, o_vec3 vector, const o_object *f, double *t)
 {
     o_vec3 p = v3(f->point), n = v3(f->normal);
@@ -231,6 +246,24 @@ int o_distance_from_prime(o_vec3 origin, o_vec3 vector, const o_object *f, doubl
         double h = sqrt((r2 - d2) / a);
         double t1 = -m - h;
         *t = (0.0 < t1) ? t1 : -m + h;
+        return 1;
+    }
+    case O_RECTANGLE: {
+        /* EXTENSION -- the reference's own attempt stops at an empty `guard`
+         * (src/Object.hs:172-175); what it has is kept: the GUARDED plane distance
+         * through the centre, then the hit point, as for a Disk.  Inside when
+         * |(hit - c).u| < _width/2 and |(hit - c).w| < _height/2, strict like the
+         * Disk's `<`; a side that is not positive is never hit. */
+        double d;
+        plane_prime(origin, vector, p, n, &d);
+        if (!guard_t(d)) return 0;
+        o_vec3 hit = o_march(origin, vector, d);
+        o_vec3 u, w;
+        o_rectangle_axes(f, &u, &w);
+        o_vec3 rel = vsub(hit, p);
+        if (!(fabs(o_dot(rel, u)) < f->extent[1] / 2.0)) return 0;
+        if (!(fabs(o_dot(rel, w)) < f->extent[0] / 2.0)) return 0;
+        *t = d;
         return 1;
     }
     default:

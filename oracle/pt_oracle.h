@@ -45,7 +45,8 @@ o_vec3 o_rotate_abs(o_vec3 v, double theta, double phi);      /* src/Util.hs:131
 o_vec3 o_rotate_rel(double theta, double phi, o_vec3 v);      /* src/Util.hs:140-145 */
 
 /* ---- Object.hs ---------------------------------------------------------- */
-enum { O_INFINITE_PLANE = 0, O_DISK = 1, O_SPHERE = 2 /* extension, no reference */ };
+enum { O_INFINITE_PLANE = 0, O_DISK = 1, O_SPHERE = 2 /* extension, no reference */,
+       O_RECTANGLE = 3 /* extension: commented out in the reference, src/Object.hs:57-61, :172-175 */ };
 
 /* Same field order and meaning as the C ABI's pt_object (include/pt.h) so a
  * test can hand one byte image to both. */
@@ -57,6 +58,7 @@ typedef struct {
     double  radius;      /* _radius            src/Object.hs:54    */
     double  color[3];    /* _color             src/Object.hs:31    */
     double  emittance;   /* _emittance         src/Object.hs:32    */
+    double  extent[2];   /* O_RECTANGLE: { _height, _width }  src/Object.hs:60-61 (commented out there) */
 } o_object;
 
 /* The reference's hard-coded scene: objects = [infPlane, infPlane2, infPlane3,
@@ -69,6 +71,8 @@ int o_distance_from_prime(o_vec3 origin, o_vec3 vector, const o_object *form, do
 /* getNormal (src/Object.hs:180-183); for the O_SPHERE extension the outward normal at `point`. */
 o_vec3 o_normal_at(const o_object *form, o_vec3 point);
 int o_distance_from(o_vec3 origin, o_vec3 vector, const o_object *form, double *t);
+/* O_RECTANGLE (extension): the unit vectors its _width (u) and _height (w) sides run along */
+void o_rectangle_axes(const o_object *form, o_vec3 *u, o_vec3 *w);
 o_vec3 o_march(o_vec3 origin, o_vec3 vector, double t);       /* src/Object.hs:151-153 */
 
 /* ---- random number streams --------------------------------------------- */

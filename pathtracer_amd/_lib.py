@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("PT_LIBPT_PATH") or os.path.join(_HERE, "libpt.so")   
 
 PT_OK = 0
 PT_ERR_INVALID, PT_ERR_NO_DEVICE, PT_ERR_HIP, PT_ERR_NO_SCENE, PT_ERR_LIMIT = -1, -2, -3, -4, -5
-PT_INFINITE_PLANE, PT_DISK, PT_SPHERE = 0, 1, 2
+PT_INFINITE_PLANE, PT_DISK, PT_SPHERE, PT_RECTANGLE = 0, 1, 2, 3
 PT_RGB8_REFERENCE, PT_RGB8_MEAN_CLAMP, PT_RGB8_MEAN_GAMMA = 0, 1, 2
 PT_FLAG_NO_PRIMARY_REUSE = 1
 PT_FLAG_LDS_TILES = 2
@@ -30,6 +30,7 @@ class pt_object(C.Structure):
         ("radius", C.c_double),
         ("color", C.c_double * 3),
         ("emittance", C.c_double),
+        ("extent", C.c_double * 2),
     ]
 
 

@@ -26,6 +26,7 @@ struct pt_ctx {
     bool canvas_stale = false;                   // pt_reset defers the zeroing to the next pt_trace / read
     float4 *d_geom = nullptr, *d_mat = nullptr;
     double *d_prim = nullptr;
+    float4 *d_rect = nullptr;          // sides of Rectangle forms, 2 float4 per object; null without one
     float4 *d_bvh_nodes = nullptr;               // spatial index over the finite forms (pt_bvh.hpp), or null
     int32_t *d_bvh_prims = nullptr;
     float4 *d_bvh_geom = nullptr;
@@ -101,8 +102,10 @@ void to_spherical_(d3 vec, double &theta, double &phi)
     phi = a;
 }
 
-void flatten_object(const pt_object &ob, float4 *geom3, float4 *mat4, double *prim)
+void flatten_object(const pt_object &ob, float4 *geom3, float4 *mat4, double *prim, float4 *rect2 = nullptr)
 {
+    for (int q = 11; q < PRIM_DOUBLES; ++q) prim[q] = 0.0;
+    if (rect2) rect2[0] = rect2[1] = make_float4(0.f, 0.f, 0.f, 0.f);
     const d3 p{ob.point[0], ob.point[1], ob.point[2]};
     const d3 n{ob.normal[0], ob.normal[1], ob.normal[2]};
     const d3 nh = normalize_(n);
@@ -152,6 +155,24 @@ void flatten_object(const pt_object &ob, float4 *geom3, float4 *mat4, double *pr
     prim[6] = nh.x; prim[7] = nh.y; prim[8] = nh.z;
     prim[9] = ob.radius;
     prim[10] = disk ? 1.0 : 0.0;
+
+    if (ob.kind == PT_RECTANGLE) {
+        // Extension (commented out in the reference, src/Object.hs:57-61, :172-175; include/pt.h defines it):
+        // the sides run along rotateAbs (1,0,0) and rotateAbs (0,1,0) (src/Util.hs:131-138), evaluated as
+        // o_rectangle_axes does.  The device tests |d.(u/hw)| < 1; the fp64 primary pass |d.u| < hw.
+        const double hh = ob.extent[0] / 2.0, hw = ob.extent[1] / 2.0;
+        const bool live = hw > 0.0 && hh > 0.0;
+        const double u[3] = {ct * cp, sp * ct, -st}, w[3] = {-sp, cp, 0.0};
+        // r2 = NaN marks the form for inside_form; a side that is not positive is a disk of radius 0: never hit
+        geom3[1].w = live ? std::numeric_limits<float>::quiet_NaN() : 0.0f;
+        if (rect2 && live) {
+            rect2[0] = make_float4((float)(u[0] / hw), (float)(u[1] / hw), (float)(u[2] / hw), 0.f);
+            rect2[1] = make_float4((float)(w[0] / hh), (float)(w[1] / hh), (float)(w[2] / hh), 0.f);
+        }
+        prim[10] = 3.0;
+        for (int q = 0; q < 3; ++q) { prim[11 + q] = u[q]; prim[14 + q] = w[q]; }
+        prim[17] = hw; prim[18] = hh;
+    }
 }
 
 template <typename T> struct DevBuf {
@@ -250,6 +271,7 @@ void pt_destroy(pt_ctx *c)
     if (c->d_geom) (void)hipFree(c->d_geom);
     if (c->d_mat) (void)hipFree(c->d_mat);
     if (c->d_prim) (void)hipFree(c->d_prim);
+    if (c->d_rect) (void)hipFree(c->d_rect);
     if (c->d_bvh_nodes) (void)hipFree(c->d_bvh_nodes);
     if (c->d_bvh_prims) (void)hipFree(c->d_bvh_prims);
     if (c->d_bvh_geom) (void)hipFree(c->d_bvh_geom);
@@ -266,7 +288,7 @@ int pt_scene_upload(pt_ctx *c, const pt_object *objs, int32_t n)
     if (!objs) return fail(c, PT_ERR_INVALID, "pt_scene_upload: null objects");
     if (n < 1 || n > MAX_OBJECTS) return fail(c, PT_ERR_LIMIT, "pt_scene_upload: need 1 <= n <= 65536");
     for (int k = 0; k < n; ++k)
-        if (objs[k].kind != PT_INFINITE_PLANE && objs[k].kind != PT_DISK && objs[k].kind != PT_SPHERE)
+        if (objs[k].kind != PT_INFINITE_PLANE && objs[k].kind != PT_DISK && objs[k].kind != PT_SPHERE && objs[k].kind != PT_RECTANGLE)
             return fail(c, PT_ERR_INVALID, "pt_scene_upload: unknown Form kind");
 
     // 8 trailing records that can never be hit (n = 0 gives t = NaN): the
@@ -279,18 +301,24 @@ int pt_scene_upload(pt_ctx *c, const pt_object *objs, int32_t n)
         geom[(size_t)k * 3 + 2] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     std::vector<double> prim((size_t)n * PRIM_DOUBLES);
-    bool spec = false;
+    bool spec = false, has_rect = false;
+    for (int k = 0; k < n; ++k) has_rect = has_rect || objs[k].kind == PT_RECTANGLE;
+    std::vector<float4> rect(has_rect ? (size_t)n * 2 : 0);
     for (int k = 0; k < n; ++k) {
-        flatten_object(objs[k], &geom[(size_t)k * 3], &mat[(size_t)k * 4], &prim[(size_t)k * PRIM_DOUBLES]);
+        flatten_object(objs[k], &geom[(size_t)k * 3], &mat[(size_t)k * 4], &prim[(size_t)k * PRIM_DOUBLES],
+                       has_rect ? &rect[(size_t)k * 2] : nullptr);
         // only a non-emissive reflective object ever scatters specularly (src/Lib.hs:74-78)
         spec = spec || (objs[k].reflective && !(objs[k].emittance > 0.0));
         // a sphere's bounce builds its rotation per hit: the same general-scatter kernels
         spec = spec || objs[k].kind == PT_SPHERE;
+        // a rectangle's inside test lives in the same general kernels (inside_form<true>)
+        spec = spec || objs[k].kind == PT_RECTANGLE;
     }
     PT_HIP(c, hipStreamSynchronize(c->stream));
     if (c->d_geom) { (void)hipFree(c->d_geom); c->d_geom = nullptr; }
     if (c->d_mat) { (void)hipFree(c->d_mat); c->d_mat = nullptr; }
     if (c->d_prim) { (void)hipFree(c->d_prim); c->d_prim = nullptr; }
+    if (c->d_rect) { (void)hipFree(c->d_rect); c->d_rect = nullptr; }
     if (c->d_bvh_nodes) { (void)hipFree(c->d_bvh_nodes); c->d_bvh_nodes = nullptr; }
     if (c->d_bvh_prims) { (void)hipFree(c->d_bvh_prims); c->d_bvh_prims = nullptr; }
     if (c->d_bvh_geom) { (void)hipFree(c->d_bvh_geom); c->d_bvh_geom = nullptr; }
@@ -302,6 +330,10 @@ int pt_scene_upload(pt_ctx *c, const pt_object *objs, int32_t n)
     PT_HIP(c, hipMemcpy(c->d_geom, geom.data(), geom.size() * sizeof(float4), hipMemcpyHostToDevice));
     PT_HIP(c, hipMemcpy(c->d_mat, mat.data(), mat.size() * sizeof(float4), hipMemcpyHostToDevice));
     PT_HIP(c, hipMemcpy(c->d_prim, prim.data(), prim.size() * sizeof(double), hipMemcpyHostToDevice));
+    if (has_rect) {
+        PT_HIP(c, hipMalloc((void **)&c->d_rect, rect.size() * sizeof(float4)));
+        PT_HIP(c, hipMemcpy(c->d_rect, rect.data(), rect.size() * sizeof(float4), hipMemcpyHostToDevice));
+    }
     c->h_geom = geom;
     c->n_obj = n;
     c->has_specular = spec;
@@ -318,6 +350,13 @@ int pt_scene_upload(pt_ctx *c, const pt_object *objs, int32_t n)
             const double r = objs[k].radius > 0.0 ? objs[k].radius : 0.0;      // r <= 0 or NaN: never hit
             const double zero3[3] = {0.0, 0.0, 0.0};                           // a sphere: the full +-r box
             boxes[(size_t)k] = disk_bounds(pr, objs[k].kind == PT_SPHERE ? zero3 : pr + 6, r);
+            if (objs[k].kind == PT_RECTANGLE) {                                // corners c +- hw u +- hh w
+                const double hw = pr[17] > 0.0 ? pr[17] : 0.0, hh = pr[18] > 0.0 ? pr[18] : 0.0;
+                for (int a = 0; a < 3; ++a) {
+                    const double h = hw * std::fabs(pr[11 + a]) + hh * std::fabs(pr[14 + a]);
+                    boxes[(size_t)k].lo[a] = pr[a] - h; boxes[(size_t)k].hi[a] = pr[a] + h;
+                }
+            }
             for (int a = 0; a < 3; ++a)
                 extent = std::max(extent, std::max(std::fabs(boxes[(size_t)k].lo[a]), std::fabs(boxes[(size_t)k].hi[a])));
             finite.push_back(k);
@@ -352,7 +391,7 @@ int pt_scene_upload(pt_ctx *c, const pt_object *objs, int32_t n)
 // the fields of TraceArgs that describe the scene
 static void scene_args(const pt_ctx *c, TraceArgs &a)
 {
-    a.geom = c->d_geom; a.mat = c->d_mat; a.prim = c->d_prim;
+    a.geom = c->d_geom; a.mat = c->d_mat; a.prim = c->d_prim; a.rect = c->d_rect;
     a.camera_depth = c->p.camera_depth;
     a.n_obj = c->n_obj; a.height = c->p.height; a.width = c->p.width;
     a.bvh_nodes = c->d_bvh_nodes; a.bvh_prims = c->d_bvh_prims; a.bvh_geom = c->d_bvh_geom;
@@ -616,14 +655,14 @@ int pt_dev_distance(pt_ctx *c, int32_t n, const pt_object *obj, const float *ori
 {
     if (int s = check_ctx(c)) return s;
     if (n < 1 || !obj || !origin || !vector || !t_out) return fail(c, PT_ERR_INVALID, "pt_dev_distance: bad argument");
-    if (obj->kind != PT_INFINITE_PLANE && obj->kind != PT_DISK && obj->kind != PT_SPHERE)
+    if (obj->kind != PT_INFINITE_PLANE && obj->kind != PT_DISK && obj->kind != PT_SPHERE && obj->kind != PT_RECTANGLE)
         return fail(c, PT_ERR_INVALID, "pt_dev_distance: unknown Form kind");
-    float4 g[3], m[4]; double prim[PRIM_DOUBLES];
-    flatten_object(*obj, g, m, prim);
+    float4 g[5], m[4]; double prim[PRIM_DOUBLES];                          // geometry record + the Rectangle sides
+    flatten_object(*obj, g, m, prim, g + 3);
     DevBuf<float4> dg; DevBuf<float> dorg, dv, dt;
-    PT_HIP(c, dg.alloc(3)); PT_HIP(c, dorg.alloc((size_t)n * 3)); PT_HIP(c, dv.alloc((size_t)n * 3));
+    PT_HIP(c, dg.alloc(5)); PT_HIP(c, dorg.alloc((size_t)n * 3)); PT_HIP(c, dv.alloc((size_t)n * 3));
     PT_HIP(c, dt.alloc((size_t)n));
-    PT_HIP(c, dg.up(g, 3)); PT_HIP(c, dorg.up(origin, (size_t)n * 3)); PT_HIP(c, dv.up(vector, (size_t)n * 3));
+    PT_HIP(c, dg.up(g, 5)); PT_HIP(c, dorg.up(origin, (size_t)n * 3)); PT_HIP(c, dv.up(vector, (size_t)n * 3));
     PT_HIP(c, launch_dev_distance(n, dg.p, dorg.p, dv.p, dt.p, c->stream));
     PT_HIP(c, hipStreamSynchronize(c->stream));
     PT_HIP(c, dt.down(t_out, (size_t)n));

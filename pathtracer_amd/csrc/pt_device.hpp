@@ -44,7 +44,7 @@ constexpr int GEOM_FLOATS = 12;
 constexpr int MAT_FLOATS = 16;
 // fp64 record for the primary pass, 11 doubles:
 //   point[3], n_raw[3], n_hat[3] (normalize n, src/Triple.hs:66-69), radius, kind
-constexpr int PRIM_DOUBLES = 11;
+constexpr int PRIM_DOUBLES = 19;     // centre 3, normal 3, unit normal 3, radius, kind, Rectangle: u 3, w 3, half width, half height
 
 constexpr int MAX_STATIC_OBJECTS = 8;
 
@@ -265,9 +265,28 @@ __device__ __forceinline__ float sphere_t(f3 c, float r2, f3 o, f3 v)
     return (t1 > 0.0f) ? t1 : (h - m);
 }
 
+// "The hit point is on the form", given d = point - centre: a Disk's
+// distanceFromCenter < radius (src/Object.hs:169-170) as |d|^2 < r2, or -- r2 = NaN
+// marks the Rectangle extension (definition in include/pt.h at PT_RECTANGLE) --
+// |d.u| < width/2 and |d.w| < height/2, with the two axes pre-divided by the half
+// sides in rect[2k], rect[2k+1].  EXT = false compiles the Disk test alone.
+template <bool EXT>
+__device__ __forceinline__ bool inside_form(const float4 *__restrict__ rect, int k, float r2, float dx, float dy, float dz)
+{
+    if constexpr (EXT) {
+        if (r2 != r2) {
+            const float4 U = rect[2 * k], W = rect[2 * k + 1];
+            const float u = fmaf(dz, U.z, fmaf(dy, U.y, dx * U.x));
+            const float w = fmaf(dz, W.z, fmaf(dy, W.y, dx * W.x));
+            return (fabsf(u) < 1.0f) & (fabsf(w) < 1.0f);
+        }
+    }
+    return fmaf(dz, dz, fmaf(dy, dy, dx * dx)) < r2;
+}
+
 // distanceFrom (src/Object.hs:156-177) for one object against one ray.
 // Returns t, or NaN where the reference returns Nothing.
-__device__ __forceinline__ float distance_from(float4 g0, float4 g1, float4 g2, f3 o, f3 v)
+__device__ __forceinline__ float distance_from(float4 g0, float4 g1, float4 g2, const float4 *rect, f3 o, f3 v)
 {
     if (g1.w < 0.0f) {                                         // Sphere (extension)
         const float ts = sphere_t(mk3(g2.x, g2.y, g2.z), -g1.w, o, v);
@@ -282,7 +301,7 @@ __device__ __forceinline__ float distance_from(float4 g0, float4 g1, float4 g2, 
     bool ok = __float_as_uint(t) < 0x7f800000u;
     if (g1.w != __builtin_inff()) {                           // Disk, src/Object.hs:165-171
         const f3 d = mk3(fmaf(t, v.x, o.x) - g2.x, fmaf(t, v.y, o.y) - g2.y, fmaf(t, v.z, o.z) - g2.z);
-        ok = ok && (dot3(d, d) < g1.w);
+        ok = ok && inside_form<true>(rect, 0, g1.w, d.x, d.y, d.z);
     }
     return ok ? t : __builtin_nanf("");
 }
@@ -329,11 +348,17 @@ __device__ __forceinline__ void primary_candidate(const double *__restrict__ pri
         den = den + h.dz * p[8];
         t = num / den;
         ok = (0.0 < t) && (t < (double)__builtin_inff());
-        if (ok && p[10] != 0.0) {                             // Disk
+        if (ok && p[10] != 0.0) {                             // Disk, or the Rectangle extension (kind 3)
             const double px = 0.0 + t * h.dx - p[0];
             const double py = 0.0 + t * h.dy - p[1];
             const double pz = 0.0 + t * h.dz - p[2];
-            ok = sqrt(px * px + py * py + pz * pz) < p[9];
+            if (p[10] == 3.0) {
+                double du = 0.0; du = du + px * p[11]; du = du + py * p[12]; du = du + pz * p[13];
+                double dw = 0.0; dw = dw + px * p[14]; dw = dw + py * p[15]; dw = dw + pz * p[16];
+                ok = (fabs(du) < p[17]) && (fabs(dw) < p[18]);
+            } else {
+                ok = sqrt(px * px + py * py + pz * pz) < p[9];
+            }
         }
     }
     if (ok && (h.idx < 0 || t < h.t || (t == h.t && k < h.idx))) { h.idx = k; h.t = t; }

@@ -28,6 +28,7 @@ struct TraceArgs {
     const float4       *geom;          // n_obj * 3 float4   (dynamic path)
     const float4       *mat;           // n_obj * 4 float4
     const double       *prim;          // n_obj * PRIM_DOUBLES
+    const float4       *rect;          // n_obj * 2 float4, the sides of Rectangle forms (extension); null without one
     double   camera_depth;
     int      n_obj;
     int      height, width;
@@ -56,7 +57,7 @@ hipError_t launch_rgb8(const float *canvas, uint8_t *rgb, int H, int W, int mode
 hipError_t launch_dev_diffuse(int n, const float4 *mat1, const float *u, float *out, hipStream_t s);
 hipError_t launch_dev_specular(int n, const float *v, const float *nrm, const float *u,
                                float noise_rev, float *out, hipStream_t s);
-hipError_t launch_dev_distance(int n, const float4 *geom1, const float *o, const float *v,
+hipError_t launch_dev_distance(int n, const float4 *geom1_rect, const float *o, const float *v,
                                float *t, hipStream_t s);
 hipError_t launch_dev_philox(int n, const uint32_t *c0, const uint32_t *c1, uint32_t key,
                              uint32_t *out, hipStream_t s);

@@ -45,7 +45,7 @@ __device__ __forceinline__ unsigned long long *seg_lane(unsigned long long *base
 // closest-hit search (closestObjectTo, src/Lib.hs:81-98)
 // ---------------------------------------------------------------------------
 template <bool SPH>
-__device__ __forceinline__ void test_object(float4 g0, float4 g1, float4 g2, int k, f3 o, f3 v,
+__device__ __forceinline__ void test_object(float4 g0, float4 g1, float4 g2, const float4 *__restrict__ rect, int k, f3 o, f3 v,
                                             int last, int &best, float &best_t)
 {
     if constexpr (SPH) {
@@ -70,7 +70,7 @@ __device__ __forceinline__ void test_object(float4 g0, float4 g1, float4 g2, int
         const float dx = fmaf(t, v.x, o.x) - g2.x;
         const float dy = fmaf(t, v.y, o.y) - g2.y;
         const float dz = fmaf(t, v.z, o.z) - g2.z;
-        ok = ok & (fmaf(dz, dz, fmaf(dy, dy, dx * dx)) < g1.w);
+        ok = ok & inside_form<SPH>(rect, k, g1.w, dx, dy, dz);
     }
     best = ok ? k : best;
     best_t = ok ? t : best_t;
@@ -89,7 +89,7 @@ constexpr uint32_t KEY_INVALID = 0xffffffffu;
 constexpr uint32_t KEY_LIMIT   = 0x7f7fffffu;   // bits(+Inf) - 1: keys below are finite positive t
 
 template <bool SPH>
-__device__ __forceinline__ void test_object_key(float4 g0, float4 g1, float4 g2, int k, f3 o, f3 v,
+__device__ __forceinline__ void test_object_key(float4 g0, float4 g1, float4 g2, const float4 *__restrict__ rect, int k, f3 o, f3 v,
                                                 int last, int &best, uint32_t &best_key)
 {
     if constexpr (SPH) {
@@ -111,7 +111,7 @@ __device__ __forceinline__ void test_object_key(float4 g0, float4 g1, float4 g2,
         const float dx = fmaf(t, v.x, o.x) - g2.x;
         const float dy = fmaf(t, v.y, o.y) - g2.y;
         const float dz = fmaf(t, v.z, o.z) - g2.z;
-        key = (fmaf(dz, dz, fmaf(dy, dy, dx * dx)) < g1.w) ? key : KEY_INVALID;
+        key = inside_form<SPH>(rect, k, g1.w, dx, dy, dz) ? key : KEY_INVALID;
     }
     const bool better = key < best_key;
     best = better ? k : best;
@@ -163,7 +163,7 @@ __device__ __forceinline__ void closest(const TraceArgs &a, const StaticGeom<NS>
             const float dx = fmaf(t, v.x, o.x) - g2.x;         // Disk (src/Object.hs:165-171); a plane has r2 = +Inf
             const float dy = fmaf(t, v.y, o.y) - g2.y;
             const float dz = fmaf(t, v.z, o.z) - g2.z;
-            bool inside = (fmaf(dz, dz, fmaf(dy, dy, dx * dx)) < g1.w) || (g1.w == __builtin_inff());
+            bool inside = inside_form<SPH>(a.rect, k, g1.w, dx, dy, dz) || (g1.w == __builtin_inff());
             if constexpr (SPH) {                               // per lane here: both forms computed, one selected
                 const float ts = sphere_t(mk3(g2.x, g2.y, g2.z), -g1.w, o, v);
                 t = (g1.w < 0.0f) ? ts : t;
@@ -211,7 +211,7 @@ __device__ __forceinline__ void closest(const TraceArgs &a, const StaticGeom<NS>
             }
 #pragma unroll 2
             for (int k = 0; k < cnt; ++k)
-                test_object_key<SPH>(s_tile[3 * k + 0], s_tile[3 * k + 1], s_tile[3 * k + 2], base + k, o, v, last, best,
+                test_object_key<SPH>(s_tile[3 * k + 0], s_tile[3 * k + 1], s_tile[3 * k + 2], a.rect, base + k, o, v, last, best,
                                 best_key);
         }
         key_result(best, best_key, best_t);
@@ -221,7 +221,7 @@ __device__ __forceinline__ void closest(const TraceArgs &a, const StaticGeom<NS>
         // the host pads the list to NS with objects that can never be hit
 #pragma unroll
         for (int k = 0; k < NS; ++k)
-            test_object<SPH>(sg.g[k][0], sg.g[k][1], sg.g[k][2], k, o, v, last, best, best_t);
+            test_object<SPH>(sg.g[k][0], sg.g[k][1], sg.g[k][2], a.rect, k, o, v, last, best, best_t);
     } else {
         // Large scenes: the records stream through the scalar cache from L2/HBM.
         // Scalar loads return out of order, so the only safe wait is
@@ -238,13 +238,13 @@ __device__ __forceinline__ void closest(const TraceArgs &a, const StaticGeom<NS>
         for (int k = 0; k < n; k += 4) {
             load(B0, g + 6); load(B1, g + 9);
             __builtin_amdgcn_sched_barrier(0);             // keep the prefetch ahead of the arithmetic
-            test_object_key<SPH>(A0[0], A0[1], A0[2], k, o, v, last, best, best_key);
-            test_object_key<SPH>(A1[0], A1[1], A1[2], k + 1, o, v, last, best, best_key);
+            test_object_key<SPH>(A0[0], A0[1], A0[2], a.rect, k, o, v, last, best, best_key);
+            test_object_key<SPH>(A1[0], A1[1], A1[2], a.rect, k + 1, o, v, last, best, best_key);
             g += 12;
             load(A0, g); load(A1, g + 3);
             __builtin_amdgcn_sched_barrier(0);
-            test_object_key<SPH>(B0[0], B0[1], B0[2], k + 2, o, v, last, best, best_key);
-            test_object_key<SPH>(B1[0], B1[1], B1[2], k + 3, o, v, last, best, best_key);
+            test_object_key<SPH>(B0[0], B0[1], B0[2], a.rect, k + 2, o, v, last, best, best_key);
+            test_object_key<SPH>(B1[0], B1[1], B1[2], a.rect, k + 3, o, v, last, best, best_key);
         }
         key_result(best, best_key, best_t);
     }
@@ -660,8 +660,8 @@ __global__ __launch_bounds__(NS == -2 ? 64 : TRACE_BLOCK) void trace_steal_kerne
 //     also the Philox counter word and the loop's exit test.
 // ---------------------------------------------------------------------------
 template <int NS, bool SPH>
-__device__ __forceinline__ void closest_static(const StaticGeom<NS> &sg, f3 o, f3 v, int lastp, int &bestp,
-                                               float &best_t)
+__device__ __forceinline__ void closest_static(const StaticGeom<NS> &sg, const float4 *__restrict__ rect, f3 o, f3 v, int lastp,
+                                               int &bestp, float &best_t)
 {
     // The bits of t order the candidates as unsigned integers: finite positive t
     // below bits(+Inf); t <= -0, NaN and +Inf at or above it.  t = +0 alone would
@@ -686,7 +686,7 @@ __device__ __forceinline__ void closest_static(const StaticGeom<NS> &sg, f3 o, f
             const float dx = fmaf(t, v.x, o.x) - g2.x;
             const float dy = fmaf(t, v.y, o.y) - g2.y;
             const float dz = fmaf(t, v.z, o.z) - g2.z;
-            ok = ok & (fmaf(dz, dz, fmaf(dy, dy, dx * dx)) < g1.w);
+            ok = ok & inside_form<SPH>(rect, k, g1.w, dx, dy, dz);
         }
         bestp = ok ? 16 * (k + 1) : bestp;
         best_key = ok ? key : best_key;
@@ -792,7 +792,7 @@ __global__ __launch_bounds__(STATIC_BLOCK) void trace_static_kernel(TraceArgs a,
     // and returns in c1 the counter word (sample << 6 | 0) of a restarted path.
     auto trip = [&](auto all_alive, auto &&draw) {
         int kp; float t;
-        closest_static<NS, SPEC>(sg, o, d, lastp, kp, t);
+        closest_static<NS, SPEC>(sg, a.rect, o, d, lastp, kp, t);
         const bool live = decltype(all_alive)::value ? true : alive;
         if (!decltype(all_alive)::value) segs += live ? 1 : 0;            // phase 1 counts its trips wave-uniformly
         const float4 m0 = matp(kp, 0);
@@ -1074,7 +1074,7 @@ __global__ void dev_distance_kernel(int n, const float4 *__restrict__ g, const f
 {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
-    t[k] = distance_from(g[0], g[1], g[2], mk3(o[3 * k], o[3 * k + 1], o[3 * k + 2]),
+    t[k] = distance_from(g[0], g[1], g[2], g + 3, mk3(o[3 * k], o[3 * k + 1], o[3 * k + 2]),
                          mk3(v[3 * k], v[3 * k + 1], v[3 * k + 2]));
 }
 

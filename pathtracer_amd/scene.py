@@ -41,7 +41,15 @@ class Sphere:                   # EXTENSION: the reference only has "TODO: add s
     normal: Vec = (0.0, 0.0, 0.0)       # unused: the normal is (point - center) / radius at the hit
 
 
-Form = Union[InfinitePlane, Disk, Sphere]
+@dataclass
+class Rectangle:                # EXTENSION: commented out in the reference (src/Object.hs:57-61, :172-175);
+    center: Vec                 # include/pt.h (PT_RECTANGLE) states how the sides are oriented
+    normal: Vec
+    height: float
+    width: float
+
+
+Form = Union[InfinitePlane, Disk, Sphere, Rectangle]
 
 
 @dataclass
@@ -59,6 +67,9 @@ class Object:                   # src/Object.hs:30-36
             o.kind, pt, o.radius = _lib.PT_DISK, f.center, float(f.radius)
         elif isinstance(f, Sphere):
             o.kind, pt, o.radius = _lib.PT_SPHERE, f.center, float(f.radius)
+        elif isinstance(f, Rectangle):
+            o.kind, pt, o.radius = _lib.PT_RECTANGLE, f.center, 0.0
+            o.extent[:] = [float(f.height), float(f.width)]
         elif isinstance(f, InfinitePlane):
             o.kind, pt, o.radius = _lib.PT_INFINITE_PLANE, f.point, 0.0
         else:
@@ -98,6 +109,19 @@ def random_sphere_scene(n: int, seed: int):
     objs = random_disk_scene(n, seed)
     return [o if isinstance(o.form, InfinitePlane) else
             Object(o.color, o.emittance, o.reflective, Sphere(o.form.center, o.form.radius), o.name.replace("disk", "sphere"))
+            for o in objs]
+
+
+def random_rectangle_scene(n: int, seed: int):
+    """random_disk_scene with every disk of radius r replaced by a Rectangle of the
+    same centre and normal, height 2r and width 1.2r.  Rectangles are an extension
+    (commented out in the reference, src/Object.hs:57-61); include/pt.h
+    (PT_RECTANGLE) states their definition."""
+    objs = random_disk_scene(n, seed)
+    return [o if isinstance(o.form, InfinitePlane) else
+            Object(o.color, o.emittance, o.reflective,
+                   Rectangle(o.form.center, o.form.normal, 2.0 * o.form.radius, 1.2 * o.form.radius),
+                   o.name.replace("disk", "rectangle"))
             for o in objs]
 
 

@@ -23,7 +23,7 @@ class Vec3(C.Structure):
 class OObject(C.Structure):
     _fields_ = [("kind", C.c_int32), ("reflective", C.c_int32), ("point", C.c_double * 3),
                 ("normal", C.c_double * 3), ("radius", C.c_double), ("color", C.c_double * 3),
-                ("emittance", C.c_double)]
+                ("emittance", C.c_double), ("extent", C.c_double * 2)]
 
 
 class OParams(C.Structure):
@@ -49,6 +49,7 @@ def _load():
         "o_distance_from": (C.c_int, [v, v, C.POINTER(OObject), C.POINTER(d)]),
         "o_march": (v, [v, v, d]),
         "o_normal_at": (v, [C.POINTER(OObject), v]),
+        "o_rectangle_axes": (None, [C.POINTER(OObject), C.POINTER(v), C.POINTER(v)]),
         "o_mk_stdgen": (StdGen, [C.c_int64]), "o_stdgen_next": (C.c_int32, [C.POINTER(StdGen)]),
         "o_stdgen_random_int": (C.c_int64, [C.POINTER(StdGen)]),
         "o_stdgen_random_double": (d, [C.POINTER(StdGen)]),

@@ -33,13 +33,13 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(raw, name), f"libpt.so does not export {name}"
         assert name in _lib.SIGNATURES, f"pathtracer_amd._lib has no signature for {name}"
     assert set(_lib.SIGNATURES) == set(declared_functions())
-    assert raw.pt_abi_version() == 1
+    assert raw.pt_abi_version() == 2
 
 
 def test_struct_layouts_match_the_header():
     from pathtracer_amd import _lib
     import oracle as O
-    assert C.sizeof(_lib.pt_object) == 4 + 4 + 8 * 3 + 8 * 3 + 8 + 8 * 3 + 8 == 96
+    assert C.sizeof(_lib.pt_object) == 4 + 4 + 8 * 3 + 8 * 3 + 8 + 8 * 3 + 8 + 8 * 2 == 112
     assert C.sizeof(_lib.pt_params) == 40
     assert C.sizeof(O.OObject) == C.sizeof(_lib.pt_object)      # tests hand one byte image to both
 
