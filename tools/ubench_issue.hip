@@ -181,6 +181,49 @@ ALL(DEF)
 #define DEFP(NAME, FMT, OPS) KERNELP(NAME, FMT)
 ALLP(DEFP)
 
+
+// packed-fp32 ops next to single ops: four pair accumulators (%0-%3) and four single ones (%4-%7)
+#define P_FMA(n)      "v_pk_fma_f32 %" #n ", %13, %14, %" #n "\n"
+#define P_FMA_BC(n)   "v_pk_fma_f32 %" #n ", %13, %14, %" #n " op_sel_hi:[0,1,1]\n"
+#define P_FMA_BC1(n)  "v_pk_fma_f32 %" #n ", %13, %14, %" #n " op_sel:[1,0,0] op_sel_hi:[1,1,1]\n"
+#define P_MUL_BC(n)   "v_pk_mul_f32 %" #n ", %13, %" #n " op_sel_hi:[0,1]\n"
+#define P_NONE(n)     ""
+#define S_MULV(n)     "v_mul_f32 %" #n ", %10, %" #n "\n"
+#define S_2MULV(n)    "v_mul_f32 %" #n ", %10, %" #n "\nv_mul_f32 %" #n ", %11, %" #n "\n"
+#define S_FMAV(n)     "v_fma_f32 %" #n ", %10, %11, %" #n "\n"
+#define S_FMAS(n)     "v_fma_f32 %" #n ", %8, %11, %" #n "\n"
+#define S_CMP(n)      "v_cmp_lt_f32 s[20:21], %" #n ", %10\n"
+#define S_CND(n)      "v_cndmask_b32 %" #n ", %" #n ", %10, %12\n"
+#define S_RCP(n)      "v_rcp_f32 %" #n ", %" #n "\n"
+#define S_NONE(n)     ""
+#define REP4M(pf, sf) \
+    asm volatile(pf(0) sf(4) pf(1) sf(5) pf(2) sf(6) pf(3) sf(7) \
+                 : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3) \
+                 : "s"(s0), "s"(s1), "v"(a.x), "v"(b.x), "s"(m64), "v"(a), "v"(b) : "vcc", "s20", "s21")
+#define KERNELM(NAME, PF, SF)                                                                   \
+    __global__ __launch_bounds__(256) void NAME(float *out, float s0, float s1, u64 m64, u64 *cyc) \
+    {                                                                                           \
+        typedef float v2f __attribute__((ext_vector_type(2)));                                  \
+        v2f a = {1.0001f + threadIdx.x * 1e-6f, 0.999f}, b = {0.5f, 0.25f};                      \
+        v2f p0 = {(float)threadIdx.x, 1.f}, p1 = p0 + 1, p2 = p0 + 2, p3 = p0 + 3;              \
+        float q0 = threadIdx.x + 4, q1 = q0 + 1, q2 = q0 + 2, q3 = q0 + 3;                      \
+        const u64 t0 = __builtin_readcyclecounter();                                            \
+        for (int it = 0; it < N_ITERS; ++it) {                                                  \
+            REP4M(PF, SF); REP4M(PF, SF); REP4M(PF, SF); REP4M(PF, SF);                          \
+            REP4M(PF, SF); REP4M(PF, SF); REP4M(PF, SF); REP4M(PF, SF); }                        \
+        const u64 t1 = __builtin_readcyclecounter();                                            \
+        v2f r = p0 + p1 + p2 + p3;                                                              \
+        out[blockIdx.x * 256 + threadIdx.x] = r.x + r.y + q0 + q1 + q2 + q3;                    \
+        if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 4 + threadIdx.x / 64] = t1 - t0;          \
+    }
+// OPS = instructions per (pf, sf) pair
+#define ALLM(X) X(m_pk_only, P_FMA, S_NONE, 1) X(m_pk_bc, P_FMA_BC, S_NONE, 1) X(m_pk_bc1, P_FMA_BC1, S_NONE, 1) \
+    X(m_pkmul_bc, P_MUL_BC, S_NONE, 1) X(m_pk_mulv, P_FMA, S_MULV, 2) X(m_pk_2mulv, P_FMA, S_2MULV, 3) \
+    X(m_pk_fmav, P_FMA, S_FMAV, 2) X(m_pk_fmas, P_FMA, S_FMAS, 2) X(m_pk_cmp, P_FMA, S_CMP, 2) X(m_pk_cnd, P_FMA, S_CND, 2) \
+    X(m_pk_rcp, P_FMA, S_RCP, 2) X(m_pkbc_mulv, P_FMA_BC, S_MULV, 2) X(m_fmav_only, P_NONE, S_FMAV, 1)
+#define DEFM(NAME, PF, SF, OPS) KERNELM(NAME, PF, SF)
+ALLM(DEFM)
+
 static float *d_out;
 static u64 *d_cyc;
 template <typename K> void run(K kern, const char *name, double ops, int waves_per_simd)
@@ -210,6 +253,8 @@ int main(int argc, char **argv)
 #define RUN(NAME, FMT, OPS) run(NAME, #NAME, OPS, w);
     ALL(RUN)
     ALLP(RUN)
+#define RUNM(NAME, PF, SF, OPS) run(NAME, #NAME, OPS, w);
+    ALLM(RUNM)
     run(k_mad64, "k_mad64", 1, w);
     hipFree(d_out);
     return 0;
