@@ -278,7 +278,7 @@ __device__ __forceinline__ bool inside_form(const float4 *__restrict__ rect, int
             const float4 U = rect[2 * k], W = rect[2 * k + 1];
             const float u = fmaf(dz, U.z, fmaf(dy, U.y, dx * U.x));
             const float w = fmaf(dz, W.z, fmaf(dy, W.y, dx * W.x));
-            return (fabsf(u) < 1.0f) & (fabsf(w) < 1.0f);
+            return fabsf(u) < 1.0f && fabsf(w) < 1.0f;
         }
     }
     return fmaf(dz, dz, fmaf(dy, dy, dx * dx)) < r2;

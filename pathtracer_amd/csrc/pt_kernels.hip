@@ -659,8 +659,13 @@ __global__ __launch_bounds__(NS == -2 ? 64 : TRACE_BLOCK) void trace_steal_kerne
 //   * sample index and bounce live in one counter (gs << 6 | bounce) that is
 //     also the Philox counter word and the loop's exit test.
 // ---------------------------------------------------------------------------
-template <int NS, bool SPH>
+// MASKS: the _lastStruck exclusion arrives as one lane mask per object
+// (excl[k] = lanes whose last-struck object is k) and every accept decision is
+// returned as a lane mask (okm[k]); the caller derives the next masks from them
+// on the scalar unit, so the search spends no vector compare on identity.
+template <int NS, bool SPH, bool MASKS>
 __device__ __forceinline__ void closest_static(const StaticGeom<NS> &sg, const float4 *__restrict__ rect, f3 o, f3 v, int lastp,
+                                               const unsigned long long *excl, unsigned long long *okm,
                                                int &bestp, float &best_t)
 {
     // The bits of t order the candidates as unsigned integers: finite positive t
@@ -681,13 +686,20 @@ __device__ __forceinline__ void closest_static(const StaticGeom<NS> &sg, const f
                 t = fmaf(sphere_t(mk3(g2.x, g2.y, g2.z), -g1.w, o, v), 1.0f, -__builtin_bit_cast(float, 1u));
         }
         const uint32_t key = __float_as_uint(t);
-        bool ok = (key < best_key) & (16 * (k + 1) != lastp);     // 0 < t < best, not _lastStruck (src/Lib.hs:86-90)
+        // 0 < t < best, not _lastStruck (src/Lib.hs:86-90)
+        bool ok = false;
+        unsigned long long m = 0;
+        if constexpr (MASKS) m = __builtin_amdgcn_ballot_w64(key < best_key) & ~excl[k];
+        else ok = (key < best_key) & (16 * (k + 1) != lastp);
         if (g1.w != __builtin_inff() && !(SPH && g1.w < 0.0f)) {   // wave-uniform: Disk (src/Object.hs:165-171)
             const float dx = fmaf(t, v.x, o.x) - g2.x;
             const float dy = fmaf(t, v.y, o.y) - g2.y;
             const float dz = fmaf(t, v.z, o.z) - g2.z;
-            ok = ok & inside_form<SPH>(rect, k, g1.w, dx, dy, dz);
+            const bool in = inside_form<SPH>(rect, k, g1.w, dx, dy, dz);
+            if constexpr (MASKS) m &= __builtin_amdgcn_ballot_w64(in);
+            else ok = ok & in;
         }
+        if constexpr (MASKS) { okm[k] = m; ok = __builtin_amdgcn_inverse_ballot_w64(m); }
         bestp = ok ? 16 * (k + 1) : bestp;
         best_key = ok ? key : best_key;
     }
@@ -767,6 +779,16 @@ __global__ __launch_bounds__(STATIC_BLOCK) void trace_static_kernel(TraceArgs a,
     uint64_t pre = (uint64_t)0xD256D193u * (uint64_t)(uint32_t)pc;
     f3 o = cP0, d = cd0, thr = ccol;
     int lastp = cidxp;
+    // lane masks of "the primary object is k" and "the last-struck object is k" (closest_static, MASKS)
+    constexpr bool MASKS = NS <= 4;
+    unsigned long long prim_is[NS], excl[NS];
+    auto primary_masks = [&]() {
+#pragma unroll
+        for (int k = 0; k < NS; ++k) prim_is[k] = __builtin_amdgcn_ballot_w64(cidxp == 16 * (k + 1));
+    };
+    primary_masks();
+#pragma unroll
+    for (int k = 0; k < NS; ++k) excl[k] = prim_is[k];
     uint32_t ctr = (a.sample_begin << 6) | 1u;             // (global sample << 6) | segments searched on this path
     bool alive = traced;                                   // has a path in flight
     const PhiloxRegs pregs = philox_regs(a.seed);
@@ -792,12 +814,21 @@ __global__ __launch_bounds__(STATIC_BLOCK) void trace_static_kernel(TraceArgs a,
     // and returns in c1 the counter word (sample << 6 | 0) of a restarted path.
     auto trip = [&](auto all_alive, auto &&draw) {
         int kp; float t;
-        closest_static<NS, SPEC>(sg, a.rect, o, d, lastp, kp, t);
+        unsigned long long okm[NS];
+        closest_static<NS, SPEC, MASKS>(sg, a.rect, o, d, lastp, excl, okm, kp, t);
         const bool live = decltype(all_alive)::value ? true : alive;
         if (!decltype(all_alive)::value) segs += live ? 1 : 0;            // phase 1 counts its trips wave-uniformly
         const float4 m0 = matp(kp, 0);
         // miss (tag 0, src/Lib.hs:72), light (tag e > 0, :74) or the depth cap (:68) end the path
-        bool terminal = live && ((m0.w >= 0.f) || ((ctr & 63u) + 1u >= B));
+        bool terminal;
+        unsigned long long tm = 0;
+        if constexpr (MASKS) {                             // the same decision as a lane mask (see below)
+            tm = __builtin_amdgcn_ballot_w64(m0.w >= 0.f) | __builtin_amdgcn_ballot_w64((ctr & 63u) + 1u >= B);
+            if (!decltype(all_alive)::value) tm &= __builtin_amdgcn_ballot_w64(live);
+            terminal = __builtin_amdgcn_inverse_ballot_w64(tm);
+        } else {
+            terminal = live && ((m0.w >= 0.f) || ((ctr & 63u) + 1u >= B));
+        }
         {                                                  // emittance * pixel (src/Lib.hs:74); max(tag, 0) is 0 unless a light
             float E = __int_as_float(max(__float_as_int(m0.w), 0));
             if (!decltype(all_alive)::value) E = live ? E : 0.f;
@@ -818,6 +849,18 @@ __global__ __launch_bounds__(STATIC_BLOCK) void trace_static_kernel(TraceArgs a,
                   terminal ? ccol.z : thr.z * m0.z);
         d = scatter(idxp, e, din, c1, hp);
         o = hp; lastp = idxp; ctr = c1 + 1u;
+        if constexpr (MASKS) {
+            // next trip's _lastStruck masks: the primary object where the path restarts, else this
+            // trip's winner = the LAST object that was accepted
+            if (!decltype(all_alive)::value) tm = __builtin_amdgcn_ballot_w64(terminal);   // phase 2's draw rewrites it
+            unsigned long long later = 0;
+#pragma unroll
+            for (int k = NS - 1; k >= 0; --k) {
+                const unsigned long long won = okm[k] & ~later;
+                later |= okm[k];
+                excl[k] = (tm & prim_is[k]) | (won & ~tm);
+            }
+        }
     };
 
     if (alive) d = scatter(cidxp, ce, cd0, ctr - 1u, cP0);
@@ -851,6 +894,7 @@ __global__ __launch_bounds__(STATIC_BLOCK) void trace_static_kernel(TraceArgs a,
             if (terminal) g = atomicAdd(&s_next[cur], stride);           // next sample of my current pixel
             const bool want = terminal || !alive;          // lanes that need a (new) path
             bool needy = want && !(terminal && g < gs_end);
+            const bool adopting = !dry && __ballot(needy) != 0ull;
             while (!dry && __ballot(needy) != 0ull) {
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
                 const bool has = __hip_atomic_load(&s_next[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < gs_end;
@@ -875,6 +919,7 @@ __global__ __launch_bounds__(STATIC_BLOCK) void trace_static_kernel(TraceArgs a,
                     }
                 }
             }
+            if (MASKS && adopting) primary_masks();        // lanes may have moved to another pixel
             alive = !want || !needy;                       // path continues, or a sample was drawn
             terminal = want && !needy;                     // restart from the (current) pixel's primary hit
             if (terminal) c1 = g << 6;
