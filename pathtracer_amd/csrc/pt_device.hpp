@@ -173,9 +173,10 @@ __device__ __forceinline__ f3 scatter_diffuse_bits(float4 m1, float4 m2, float m
     const float theta_rev = __uint_as_float((r0 & U1_MASK) | 0x3f800000u);
     const float f = __uint_as_float((r1 & U2_MASK) | 0x3f800000u);
     const f3 l = local_dir(theta_rev, fmaf(f, PHI_REV, -PHI_REV));
+    // the last row of rotateAbs has no y term (r.z = -sin theta' x + cos theta' z, src/Util.hs:137): M[2][1] = m2.w is 0
     return mk3(fmaf(m1.z, l.z, fmaf(m1.y, l.y, m1.x * l.x)),
                fmaf(m2.y, l.z, fmaf(m2.x, l.y, m1.w * l.x)),
-               fmaf(m22,  l.z, fmaf(m2.w, l.y, m2.z * l.x)));
+               fmaf(m22,  l.z, m2.z * l.x));
 }
 
 // asin(x)/(2*pi) for x in [0,1], in revolutions.  Abramowitz-Stegun 4.4.46

@@ -748,6 +748,7 @@ __global__ __launch_bounds__(STATIC_BLOCK) void trace_static_kernel(TraceArgs a,
     const int pc = in_canvas ? pixel0 + tid : 0;
     const int pi = pc / a.width, pj = pc - pi * a.width;
     const uint32_t B = (uint32_t)a.max_bounces;
+    const uint32_t Bm1 = B - 1u;                    // 1 <= maxBounces (pt_create): the depth cap as one compare
     const uint32_t stride = a.sample_stride;
     const uint32_t gs_end = a.sample_begin + (uint32_t)a.n_samples * stride;   // first sample index beyond this launch
     const uint32_t ctr_end = gs_end << 6;
@@ -823,11 +824,11 @@ __global__ __launch_bounds__(STATIC_BLOCK) void trace_static_kernel(TraceArgs a,
         bool terminal;
         unsigned long long tm = 0;
         if constexpr (MASKS) {                             // the same decision as a lane mask (see below)
-            tm = __builtin_amdgcn_ballot_w64(m0.w >= 0.f) | __builtin_amdgcn_ballot_w64((ctr & 63u) + 1u >= B);
+            tm = __builtin_amdgcn_ballot_w64(m0.w >= 0.f) | __builtin_amdgcn_ballot_w64((ctr & 63u) >= Bm1);
             if (!decltype(all_alive)::value) tm &= __builtin_amdgcn_ballot_w64(live);
             terminal = __builtin_amdgcn_inverse_ballot_w64(tm);
         } else {
-            terminal = live && ((m0.w >= 0.f) || ((ctr & 63u) + 1u >= B));
+            terminal = live && ((m0.w >= 0.f) || ((ctr & 63u) >= Bm1));
         }
         {                                                  // emittance * pixel (src/Lib.hs:74); max(tag, 0) is 0 unless a light
             float E = __int_as_float(max(__float_as_int(m0.w), 0));
