@@ -58,9 +58,9 @@ __device__ __forceinline__ void test_object(float4 g0, float4 g1, float4 g2, con
         }
     }
     // t = (A - o.n_raw) / (v.n_hat); every object operand is wave-uniform (SGPR)
-    const float on  = fmaf(o.z, g0.z, fmaf(o.y, g0.y, o.x * g0.x));
+    const float num = fmaf(-o.z, g0.z, fmaf(-o.y, g0.y, fmaf(-o.x, g0.x, g0.w)));   // A - o.n_raw, the dot folded into A
     const float den = fmaf(v.z, g1.z, fmaf(v.y, g1.y, v.x * g1.x));
-    const float t = (g0.w - on) * __builtin_amdgcn_rcpf(den);
+    const float t = num * __builtin_amdgcn_rcpf(den);
     // 0 < t < Inf (src/Object.hs:159), not the last-struck object
     // (src/Lib.hs:86-90), strictly closer than the best so far: an equal t
     // keeps the earlier object, as Data.Vector.minimumBy does.  Plain '&' so
@@ -102,9 +102,9 @@ __device__ __forceinline__ void test_object_key(float4 g0, float4 g1, float4 g2,
             return;
         }
     }
-    const float on  = fmaf(o.z, g0.z, fmaf(o.y, g0.y, o.x * g0.x));
+    const float num = fmaf(-o.z, g0.z, fmaf(-o.y, g0.y, fmaf(-o.x, g0.x, g0.w)));   // A - o.n_raw, the dot folded into A
     const float den = fmaf(v.z, g1.z, fmaf(v.y, g1.y, v.x * g1.x));
-    const float t = (g0.w - on) * __builtin_amdgcn_rcpf(den);
+    const float t = num * __builtin_amdgcn_rcpf(den);
     uint32_t key = __float_as_uint(t) - 1u;
     key = (k == last) ? KEY_INVALID : key;                // _lastStruck (src/Lib.hs:86-90)
     if (g1.w != __builtin_inff()) {                       // wave-uniform: Disk (src/Object.hs:165-171)
@@ -157,9 +157,9 @@ __device__ __forceinline__ void closest(const TraceArgs &a, const StaticGeom<NS>
         float bt = __builtin_inff();
         auto test = [&](float4 g0, float4 g1, float4 g2, bool on) {
             const int k = __float_as_int(g2.w);
-            const float onr = fmaf(o.z, g0.z, fmaf(o.y, g0.y, o.x * g0.x));
+            const float num = fmaf(-o.z, g0.z, fmaf(-o.y, g0.y, fmaf(-o.x, g0.x, g0.w)));
             const float den = fmaf(v.z, g1.z, fmaf(v.y, g1.y, v.x * g1.x));
-            float t = (g0.w - onr) * __builtin_amdgcn_rcpf(den);
+            float t = num * __builtin_amdgcn_rcpf(den);
             const float dx = fmaf(t, v.x, o.x) - g2.x;         // Disk (src/Object.hs:165-171); a plane has r2 = +Inf
             const float dy = fmaf(t, v.y, o.y) - g2.y;
             const float dz = fmaf(t, v.z, o.z) - g2.z;
@@ -678,9 +678,11 @@ __device__ __forceinline__ void closest_static(const StaticGeom<NS> &sg, const f
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
         const float4 g0 = sg.g[k][0], g1 = sg.g[k][1], g2 = sg.g[k][2];
-        const float on  = fmaf(o.z, g0.z, fmaf(o.y, g0.y, o.x * g0.x));
+        // A - o.n_raw with the dot folded into A (g0.xyz holds -n_raw here, see the kernel's set-up): the
+        // same three roundings as distance_from's fma(-o, n, .) chain
+        const float num = fmaf(o.z, g0.z, fmaf(o.y, g0.y, fmaf(o.x, g0.x, g0.w)));
         const float den = fmaf(v.z, g1.z, fmaf(v.y, g1.y, v.x * g1.x));
-        float t = fmaf(g0.w - on, __builtin_amdgcn_rcpf(den), -__builtin_bit_cast(float, 1u));
+        float t = fmaf(num, __builtin_amdgcn_rcpf(den), -__builtin_bit_cast(float, 1u));
         if constexpr (SPH) {
             if (g1.w < 0.0f)                                       // wave-uniform: Sphere (extension)
                 t = fmaf(sphere_t(mk3(g2.x, g2.y, g2.z), -g1.w, o, v), 1.0f, -__builtin_bit_cast(float, 1u));
@@ -735,10 +737,13 @@ __global__ __launch_bounds__(STATIC_BLOCK) void trace_static_kernel(TraceArgs a,
     auto matp = [&](int p, int f) -> float4 {       // p = 16*(k+1): byte offset of the record within a field
         return *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s_mat) + p + f * R * 16);
     };
-    {   // n_raw and A to VGPRs (see the header comment)
+    {   // -n_raw and A to VGPRs (see the header comment; negated so that A - o.n_raw is one fma chain)
         auto fv = [](float &x) { x = __uint_as_float(to_vgpr(__float_as_uint(x))); };
 #pragma unroll
-        for (int k = 0; k < NS; ++k) { fv(sg.g[k][0].x); fv(sg.g[k][0].y); fv(sg.g[k][0].z); fv(sg.g[k][0].w); }
+        for (int k = 0; k < NS; ++k) {
+            sg.g[k][0].x = -sg.g[k][0].x; sg.g[k][0].y = -sg.g[k][0].y; sg.g[k][0].z = -sg.g[k][0].z;
+            fv(sg.g[k][0].x); fv(sg.g[k][0].y); fv(sg.g[k][0].z); fv(sg.g[k][0].w);
+        }
     }
 
     const int wbase = tid & ~63;
