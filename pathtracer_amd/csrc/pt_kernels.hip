@@ -816,8 +816,8 @@ __global__ __launch_bounds__(STATIC_BLOCK) void trace_static_kernel(TraceArgs a,
         }
         return scatter_diffuse_bits(matp(idxp, 1), matp(idxp, 2), matp(idxp, 3).x, r0, r1);   // src/Lib.hs:111
     };
-    // One segment.  `draw(terminal, c1)` decides what a finished path does next
-    // and returns in c1 the counter word (sample << 6 | 0) of a restarted path.
+    // One segment.  `draw(terminal, c1, c1r)` decides what a finished path does next
+    // and returns in c1r the counter word (sample << 6 | 0) of a restarted path.
     auto trip = [&](auto all_alive, auto &&draw) {
         int kp; float t;
         unsigned long long okm[NS];
@@ -842,23 +842,51 @@ __global__ __launch_bounds__(STATIC_BLOCK) void trace_static_kernel(TraceArgs a,
             acc.y = fmaf(E, thr.y, acc.y);
             acc.z = fmaf(E, thr.z, acc.z);
         }
-        uint32_t c1 = ctr;
-        draw(terminal, c1);                                // may clear or set `terminal` (= restart from cP0)
-        const int   idxp = terminal ? cidxp : kp;
-        const float e    = terminal ? ce : m0.w;
-        const f3    din  = terminal ? cd0 : d;
-        const f3 hp = mk3(terminal ? cP0.x : fmaf(t, d.x, o.x),         // march (src/Object.hs:151-153)
-                          terminal ? cP0.y : fmaf(t, d.y, o.y),
-                          terminal ? cP0.z : fmaf(t, d.z, o.z));
-        thr = mk3(terminal ? ccol.x : thr.x * m0.x,                       // pixel * color (src/Lib.hs:79)
-                  terminal ? ccol.y : thr.y * m0.y,
-                  terminal ? ccol.z : thr.z * m0.z);
+        uint32_t c1 = ctr, c1r = ctr;
+        draw(terminal, c1, c1r);                           // may clear or set `terminal` (= restart from cP0)
+        if constexpr (MASKS) {
+            if (!decltype(all_alive)::value) tm = __builtin_amdgcn_ballot_w64(terminal);   // phase 2's draw rewrites it
+        }
+        int idxp; float e; f3 din, hp;
+        if constexpr (MASKS && !SPEC) {
+            // The continuing path's values for every lane, then the restart values moved in under the lane
+            // mask: eight v_mov_b32 (plain issue class) where selects would be eight v_cndmask_b32
+            // (second-port class, the binding one in this loop; tools/ubench_issue.hip)
+            idxp = kp; e = m0.w; din = d;
+            hp = mk3(fmaf(t, d.x, o.x), fmaf(t, d.y, o.y), fmaf(t, d.z, o.z));    // march (src/Object.hs:151-153)
+            thr = mk3(thr.x * m0.x, thr.y * m0.y, thr.z * m0.z);                  // pixel * color (src/Lib.hs:79)
+            unsigned long long saved;
+            asm("s_and_saveexec_b64 %[sv], %[m]\n\t"
+                "v_mov_b32 %[i], %[ci]\n\t"
+                "v_mov_b32 %[hx], %[px]\n\t"
+                "v_mov_b32 %[hy], %[py]\n\t"
+                "v_mov_b32 %[hz], %[pz]\n\t"
+                "v_mov_b32 %[tx], %[cx]\n\t"
+                "v_mov_b32 %[ty], %[cy]\n\t"
+                "v_mov_b32 %[tz], %[cz]\n\t"
+                "v_mov_b32 %[c], %[cr]\n\t"
+                "s_mov_b64 exec, %[sv]"
+                : [i] "+v"(idxp), [hx] "+v"(hp.x), [hy] "+v"(hp.y), [hz] "+v"(hp.z), [tx] "+v"(thr.x), [ty] "+v"(thr.y),
+                  [tz] "+v"(thr.z), [c] "+v"(c1), [sv] "=&s"(saved)
+                : [m] "s"(tm), [ci] "v"(cidxp), [px] "v"(cP0.x), [py] "v"(cP0.y), [pz] "v"(cP0.z), [cx] "v"(ccol.x),
+                  [cy] "v"(ccol.y), [cz] "v"(ccol.z), [cr] "v"(c1r));
+        } else {
+            c1 = terminal ? c1r : c1;
+            idxp = terminal ? cidxp : kp;
+            e    = terminal ? ce : m0.w;
+            din  = terminal ? cd0 : d;
+            hp = mk3(terminal ? cP0.x : fmaf(t, d.x, o.x),                        // march (src/Object.hs:151-153)
+                     terminal ? cP0.y : fmaf(t, d.y, o.y),
+                     terminal ? cP0.z : fmaf(t, d.z, o.z));
+            thr = mk3(terminal ? ccol.x : thr.x * m0.x,                            // pixel * color (src/Lib.hs:79)
+                      terminal ? ccol.y : thr.y * m0.y,
+                      terminal ? ccol.z : thr.z * m0.z);
+        }
         d = scatter(idxp, e, din, c1, hp);
         o = hp; lastp = idxp; ctr = c1 + 1u;
         if constexpr (MASKS) {
             // next trip's _lastStruck masks: the primary object where the path restarts, else this
             // trip's winner = the LAST object that was accepted
-            if (!decltype(all_alive)::value) tm = __builtin_amdgcn_ballot_w64(terminal);   // phase 2's draw rewrites it
             unsigned long long later = 0;
 #pragma unroll
             for (int k = NS - 1; k >= 0; --k) {
@@ -877,8 +905,8 @@ __global__ __launch_bounds__(STATIC_BLOCK) void trace_static_kernel(TraceArgs a,
     if (__ballot(alive) == everyone) {
         uint32_t trips = 0;                                // wave-uniform
         do {
-            trip(std::true_type{}, [&](bool &terminal, uint32_t &c1) {
-                c1 = terminal ? (c1 | 63u) + next_sample : c1;
+            trip(std::true_type{}, [&](bool &terminal, uint32_t &c1, uint32_t &c1r) {
+                c1r = (c1 | 63u) + next_sample;
             });
             alive = ctr < ctr_end;                         // the sample the lane is on belongs to this launch
             trips += 1;
@@ -895,7 +923,7 @@ __global__ __launch_bounds__(STATIC_BLOCK) void trace_static_kernel(TraceArgs a,
     int cur = tid;                                         // the pixel (workgroup-relative) this lane works on
     bool dry = false;                                      // wave-uniform: no pixel has an unstarted sample
     if (__ballot(alive) != 0ull || !dry) do {
-        trip(std::false_type{}, [&](bool &terminal, uint32_t &c1) {
+        trip(std::false_type{}, [&](bool &terminal, uint32_t &c1, uint32_t &c1r) {
             uint32_t g = gs_end;
             if (terminal) g = atomicAdd(&s_next[cur], stride);           // next sample of my current pixel
             const bool want = terminal || !alive;          // lanes that need a (new) path
@@ -928,7 +956,7 @@ __global__ __launch_bounds__(STATIC_BLOCK) void trace_static_kernel(TraceArgs a,
             if (MASKS && adopting) primary_masks();        // lanes may have moved to another pixel
             alive = !want || !needy;                       // path continues, or a sample was drawn
             terminal = want && !needy;                     // restart from the (current) pixel's primary hit
-            if (terminal) c1 = g << 6;
+            c1r = g << 6;
         });
     } while (__ballot(alive) != 0ull || !dry);
 
