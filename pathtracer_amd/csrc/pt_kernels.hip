@@ -663,6 +663,20 @@ __global__ __launch_bounds__(NS == -2 ? 64 : TRACE_BLOCK) void trace_steal_kerne
 // (excl[k] = lanes whose last-struck object is k) and every accept decision is
 // returned as a lane mask (okm[k]); the caller derives the next masks from them
 // on the scalar unit, so the search spends no vector compare on identity.
+// best <- (OFF, key) in the lanes of `mask`: two plain-class moves under exec
+// instead of two second-port selects
+template <int OFF>
+__device__ __forceinline__ void take_under(unsigned long long mask, int &bestp, uint32_t &best_key, uint32_t key)
+{
+    unsigned long long saved;
+    asm("s_and_saveexec_b64 %[sv], %[m]\n\t"
+        "v_mov_b32 %[bp], %[off]\n\t"
+        "v_mov_b32 %[bk], %[key]\n\t"
+        "s_mov_b64 exec, %[sv]"
+        : [bp] "+v"(bestp), [bk] "+v"(best_key), [sv] "=&s"(saved)
+        : [m] "s"(mask), [off] "n"(OFF), [key] "v"(key));
+}
+
 template <int NS, bool SPH, bool MASKS>
 __device__ __forceinline__ void closest_static(const StaticGeom<NS> &sg, const float4 *__restrict__ rect, f3 o, f3 v, int lastp,
                                                const unsigned long long *excl, unsigned long long *okm,
@@ -701,9 +715,21 @@ __device__ __forceinline__ void closest_static(const StaticGeom<NS> &sg, const f
             if constexpr (MASKS) m &= __builtin_amdgcn_ballot_w64(in);
             else ok = ok & in;
         }
-        if constexpr (MASKS) { okm[k] = m; ok = __builtin_amdgcn_inverse_ballot_w64(m); }
-        bestp = ok ? 16 * (k + 1) : bestp;
-        best_key = ok ? key : best_key;
+        if constexpr (MASKS) {
+            okm[k] = m;
+            switch (k) {                                           // k is a constant after unrolling
+            case 0:                                                // selects from constants: they also initialise
+                ok = __builtin_amdgcn_inverse_ballot_w64(m);
+                bestp = ok ? 16 : 0; best_key = ok ? key : 0x7f800000u;
+                break;
+            case 1: take_under<32>(m, bestp, best_key, key); break;
+            case 2: take_under<48>(m, bestp, best_key, key); break;
+            default: take_under<64>(m, bestp, best_key, key); break;
+            }
+        } else {
+            bestp = ok ? 16 * (k + 1) : bestp;
+            best_key = ok ? key : best_key;
+        }
     }
     best_t = __uint_as_float(best_key);
 }
