@@ -657,7 +657,12 @@ __global__ __launch_bounds__(NS == -2 ? 64 : TRACE_BLOCK) void trace_steal_kerne
 //     reflective -2): "path ends here" is one compare and the emitted radiance
 //     max(e, 0) one integer max, with no select on hit/miss;
 //   * sample index and bounce live in one counter (gs << 6 | bounce) that is
-//     also the Philox counter word and the loop's exit test.
+//     also the Philox counter word and the loop's exit test;
+//   * (4-object list) identity and control decisions are lane masks kept on the
+//     scalar unit: _lastStruck is one mask per object, updated from the accept
+//     masks of the search with s_and/s_or/s_andn2; where such a mask exists,
+//     values are moved in under exec (v_mov_b32, plain issue class) instead of
+//     being selected (v_cndmask_b32, second-port class).
 // ---------------------------------------------------------------------------
 // MASKS: the _lastStruck exclusion arrives as one lane mask per object
 // (excl[k] = lanes whose last-struck object is k) and every accept decision is
