@@ -90,6 +90,10 @@ def main():
     ap.add_argument("--no-pipeline", action="store_true",
                     help="trace, all-reduce and output strictly in line instead of overlapped with the next frame")
     args = ap.parse_args()
+    # stdout carries exactly ONE line, the JSON: anything a library prints to file descriptor 1
+    # (RCCL's start-up banner does) goes to stderr instead
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -248,7 +252,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline and args.scene == "default":
             threads = args.cpu_threads or int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
             out["cpu_baseline"] = cpu_baseline(args.height, args.width, args.camera_depth, args.bounces, threads)
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=json_out, flush=True)
 
     for q in rs:
         q.close()
