@@ -26,6 +26,7 @@ struct pt_ctx {
     bool canvas_stale = false;                   // pt_reset defers the zeroing to the next pt_trace / read
     float4 *d_geom = nullptr, *d_mat = nullptr;
     double *d_prim = nullptr;
+    float *d_partial = nullptr;        // sample-slice planes of a launch (pt_internal.hpp), allocated at the first large pt_trace
     float4 *d_rect = nullptr;          // sides of Rectangle forms, 2 float4 per object; null without one
     float4 *d_bvh_nodes = nullptr;               // spatial index over the finite forms (pt_bvh.hpp), or null
     int32_t *d_bvh_prims = nullptr;
@@ -272,6 +273,7 @@ void pt_destroy(pt_ctx *c)
     if (c->d_mat) (void)hipFree(c->d_mat);
     if (c->d_prim) (void)hipFree(c->d_prim);
     if (c->d_rect) (void)hipFree(c->d_rect);
+    if (c->d_partial) (void)hipFree(c->d_partial);
     if (c->d_bvh_nodes) (void)hipFree(c->d_bvh_nodes);
     if (c->d_bvh_prims) (void)hipFree(c->d_bvh_prims);
     if (c->d_bvh_geom) (void)hipFree(c->d_bvh_geom);
@@ -409,6 +411,12 @@ int pt_trace(pt_ctx *c, int32_t iters)
         return fail(c, PT_ERR_LIMIT, "pt_trace: global sample index would exceed 2^26");
 
     const bool reuse = !(c->p.flags & PT_FLAG_NO_PRIMARY_REUSE);
+    // planes for the sample slices of trace_static_kernel (small scenes, default flags, large launches)
+    if (!c->d_partial && iters >= SLICE_MIN_SAMPLES && c->n_obj <= MAX_STATIC_OBJECTS && reuse && !(c->p.flags & PT_FLAG_NO_STEAL))
+        if (hipMalloc((void **)&c->d_partial, (size_t)(MAX_SLICES - 1) * npix(c) * 3 * sizeof(float)) != hipSuccess) {
+            (void)hipGetLastError();                 // no memory for the planes: launches stay unsliced
+            c->d_partial = nullptr;
+        }
     if (c->timing) PT_HIP(c, hipEventRecord(c->ev0, c->stream));
     int launches = 0;
     int32_t left = iters;
@@ -422,6 +430,7 @@ int pt_trace(pt_ctx *c, int32_t iters)
         a.sample_begin = (uint32_t)(c->p.sample_offset + c->samples_done * c->p.sample_stride);
         a.sample_stride = (uint32_t)c->p.sample_stride;
         a.n_samples = n;
+        a.partial = c->d_partial;
         PT_HIP(c, launch_trace(a, c->h_geom.data(), reuse, c->has_specular,
                                (c->p.flags & PT_FLAG_LDS_TILES) != 0,
                                (c->p.flags & PT_FLAG_NO_STEAL) == 0, c->stream));

@@ -18,6 +18,8 @@ template <int NS> struct StaticGeom {
 };
 
 // Segment counter layout: SEG_LANES 64-bit counters per epoch, one per 128-byte line.
+constexpr int MAX_SLICES = 2;
+constexpr int SLICE_MIN_SAMPLES = 256;        // smaller launches are not sliced: the second set-up pass costs what the drain saves
 constexpr int SEG_LANES = 64;
 constexpr int SEG_LANE_STRIDE = 16;                 // in counters (128 bytes)
 constexpr int SEG_EPOCH = SEG_LANES * SEG_LANE_STRIDE;
@@ -43,6 +45,12 @@ struct TraceArgs {
     const float4  *bvh_nodes;          // 1 float4 per node: six binary16 box bounds + code (pt_bvh.hpp)
     const int32_t *bvh_prims;          // [unbounded objects..., finite objects in leaf order...]
     const float4  *bvh_geom;           // geometry records in bvh_prims order (3 float4 each, object index in [2].w), padded
+    // Sample slices of one launch (trace_static_kernel): slice y = blockIdx.y traces samples
+    // [slice_j0[y], slice_j0[y] + slice_n[y]) of the launch's n_samples; slice 0 continues the canvas, slice
+    // y > 0 writes plane y - 1 of `partial`, and slice_sum_kernel adds the planes to the canvas in order.
+    float   *partial;                  // (MAX_SLICES - 1) * H*W*3 floats, or null: no slicing
+    int      n_slices;
+    int      slice_j0[MAX_SLICES], slice_n[MAX_SLICES];
     int      n_nodes;
     int      bvh_depth;                // deepest leaf: the walk's stack holds at most this many far children
     int      n_unbounded;

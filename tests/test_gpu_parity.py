@@ -304,6 +304,35 @@ def test_work_sharing_renders_the_same_paths(pa, H, W, spp, bounces):
     assert b.sum() > 0
 
 
+@pytest.mark.parametrize("H,W,spp", [(40, 56, 256), (33, 32, 700), (64, 64, 513)])
+def test_sample_slices_of_a_large_launch(pa, H, W, spp):
+    """A launch of >= 256 samples runs as two sample slices (the last 1/16 of the
+    samples in workgroups of their own, summed into the canvas by a second kernel):
+    same paths, same count of searches, sums equal up to fp32 summation order --
+    against the strict kernel (never sliced), against two launches that are too
+    small to be sliced, and continuing a canvas that already holds samples."""
+    P = pa.Params(H, W, 500.0, spp, 8)
+    with pa.Renderer(P, seed=9) as sliced, pa.Renderer(P, seed=9, flags=pa.PT_FLAG_NO_STEAL) as strict, \
+            pa.Renderer(P, seed=9) as small, pa.Renderer(P, seed=9) as cont:
+        sliced.trace(spp)
+        strict.trace(spp)
+        k = 0
+        while k < spp:                                   # launches of < 256 samples: whole
+            n = min(200, spp - k)
+            small.trace(n); k += n
+        cont.trace(5)
+        cont.trace(spp - 5)                              # a sliced launch on top of a non-empty canvas
+        a, b, c, d = sliced.read_sum_f32(), strict.read_sum_f32(), small.read_sum_f32(), cont.read_sum_f32()
+        launches = -(-spp // 200)
+        assert sliced.segments == strict.segments
+        assert small.segments == strict.segments + (launches - 1) * H * W
+        assert cont.segments == strict.segments + H * W
+        assert sliced.samples_done == spp
+    for x in (a, c, d):
+        assert np.allclose(x, b, rtol=4e-6, atol=1e-5)
+    assert b.sum() > 0
+
+
 def test_traces_generator(pa):
     """Lib.traces: element k = sum of k samples; element 0 black; lazily extended."""
     P = pa.Params(16, 24, 500.0, 3, 4)
