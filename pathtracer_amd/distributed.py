@@ -57,6 +57,8 @@ def stream_on_another_queue(first, tries=8, spin_cycles=2_000_000):
     import torch
     spare = []
     s = None
+    if not hasattr(torch.cuda, "_sleep"):               # no spin kernel to probe with: take what the runtime gives
+        return torch.cuda.Stream(), spare
     for _ in range(tries):
         s = torch.cuda.Stream()
         t = []
