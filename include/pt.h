@@ -172,7 +172,10 @@ int pt_read_rgb8(pt_ctx *ctx, uint8_t *out, int32_t mode);
 int pt_primary_hits(pt_ctx *ctx, int32_t *idx, double *t, double *normal);
 
 /* Counters: closestObjectTo executions (src/Lib.hs:81) so far, and samples
- * per pixel added so far by this context. */
+ * per pixel added so far by this context.  The primary ray has no jitter
+ * (src/Lib.hs:41-51), so its search runs once per pixel for a camera and scene
+ * -- by the first pt_trace after pt_scene_upload on scenes of <= 8 objects with
+ * default flags, once per pt_trace otherwise -- and is counted when it runs. */
 int pt_segments(pt_ctx *ctx, uint64_t *out);
 int pt_samples_done(pt_ctx *ctx, int64_t *out);
 

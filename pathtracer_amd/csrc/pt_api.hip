@@ -26,6 +26,8 @@ struct pt_ctx {
     bool canvas_stale = false;                   // pt_reset defers the zeroing to the next pt_trace / read
     float4 *d_geom = nullptr, *d_mat = nullptr;
     double *d_prim = nullptr;
+    float4 *d_pix = nullptr;           // primary hits kept across launches (TraceArgs::pix); valid until the next scene upload
+    bool pix_valid = false;
     float *d_partial = nullptr;        // sample-slice planes of a launch (pt_internal.hpp), allocated at the first large pt_trace
     float4 *d_rect = nullptr;          // sides of Rectangle forms, 2 float4 per object; null without one
     float4 *d_bvh_nodes = nullptr;               // spatial index over the finite forms (pt_bvh.hpp), or null
@@ -274,6 +276,7 @@ void pt_destroy(pt_ctx *c)
     if (c->d_prim) (void)hipFree(c->d_prim);
     if (c->d_rect) (void)hipFree(c->d_rect);
     if (c->d_partial) (void)hipFree(c->d_partial);
+    if (c->d_pix) (void)hipFree(c->d_pix);
     if (c->d_bvh_nodes) (void)hipFree(c->d_bvh_nodes);
     if (c->d_bvh_prims) (void)hipFree(c->d_bvh_prims);
     if (c->d_bvh_geom) (void)hipFree(c->d_bvh_geom);
@@ -326,6 +329,7 @@ int pt_scene_upload(pt_ctx *c, const pt_object *objs, int32_t n)
     if (c->d_bvh_geom) { (void)hipFree(c->d_bvh_geom); c->d_bvh_geom = nullptr; }
     c->n_nodes = c->n_unbounded = 0;
     c->n_obj = 0;
+    c->pix_valid = false;
     PT_HIP(c, hipMalloc((void **)&c->d_geom, geom.size() * sizeof(float4)));
     PT_HIP(c, hipMalloc((void **)&c->d_mat, mat.size() * sizeof(float4)));
     PT_HIP(c, hipMalloc((void **)&c->d_prim, prim.size() * sizeof(double)));
@@ -417,6 +421,12 @@ int pt_trace(pt_ctx *c, int32_t iters)
             (void)hipGetLastError();                 // no memory for the planes: launches stay unsliced
             c->d_partial = nullptr;
         }
+    const bool static_path = c->n_obj <= MAX_STATIC_OBJECTS && reuse && !(c->p.flags & PT_FLAG_NO_STEAL);
+    if (static_path && !c->d_pix)
+        if (hipMalloc((void **)&c->d_pix, npix(c) * 2 * sizeof(float4)) != hipSuccess) {
+            (void)hipGetLastError();                 // no memory: every launch repeats the primary pass
+            c->d_pix = nullptr;
+        }
     if (c->timing) PT_HIP(c, hipEventRecord(c->ev0, c->stream));
     int launches = 0;
     int32_t left = iters;
@@ -431,9 +441,11 @@ int pt_trace(pt_ctx *c, int32_t iters)
         a.sample_stride = (uint32_t)c->p.sample_stride;
         a.n_samples = n;
         a.partial = c->d_partial;
+        a.pix = static_path ? c->d_pix : nullptr; a.pix_valid = a.pix && c->pix_valid ? 1 : 0;
         PT_HIP(c, launch_trace(a, c->h_geom.data(), reuse, c->has_specular,
                                (c->p.flags & PT_FLAG_LDS_TILES) != 0,
                                (c->p.flags & PT_FLAG_NO_STEAL) == 0, c->stream));
+        if (a.pix) c->pix_valid = true;              // later launches on this stream read what this one stored
         c->canvas_stale = false;
         c->samples_done += n;
         left -= n;

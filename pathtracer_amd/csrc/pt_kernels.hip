@@ -796,19 +796,33 @@ __global__ __launch_bounds__(STATIC_BLOCK) void trace_static_kernel(TraceArgs a,
     const uint32_t gs_end = sample_begin + (uint32_t)n_samples * stride;   // first sample index beyond this slice
     const uint32_t ctr_end = gs_end << 6;
 
-    unsigned long long segs = in_canvas && slice == 0 ? 1 : 0;   // the fp64 primary search below, counted once per launch
+    // the fp64 primary search below is counted once, by the launch that executes it
+    unsigned long long segs = in_canvas && slice == 0 && !a.pix_valid ? 1 : 0;
     f3 acc = mk3(0.f, 0.f, 0.f);
     if (in_canvas && !fresh) acc = mk3(canvas[3 * (size_t)pc + 0], canvas[3 * (size_t)pc + 1], canvas[3 * (size_t)pc + 2]);
 
-    // primary segment, once per pixel, fp64 (src/Lib.hs:41-51, :81-98)
-    const PrimaryHit ph = primary_hit(a, pi, pj);
-    f3 cd0 = mk3((float)ph.dx, (float)ph.dy, (float)ph.dz);
-    f3 cP0 = mk3((float)(ph.t * ph.dx), (float)(ph.t * ph.dy), (float)(ph.t * ph.dz));
+    // primary segment, once per pixel, fp64 (src/Lib.hs:41-51, :81-98); the same for every launch of this
+    // camera and scene, so the first launch leaves it in a.pix for the later ones
+    f3 cd0, cP0;
+    int cidxp;
+    if (a.pix_valid) {
+        const float4 q0 = a.pix[2 * (size_t)pc], q1 = a.pix[2 * (size_t)pc + 1];
+        cP0 = mk3(q0.x, q0.y, q0.z); cd0 = mk3(q0.w, q1.x, q1.y); cidxp = __float_as_int(q1.z);
+    } else {
+        const PrimaryHit ph = primary_hit(a, pi, pj);
+        cd0 = mk3((float)ph.dx, (float)ph.dy, (float)ph.dz);
+        cP0 = mk3((float)(ph.t * ph.dx), (float)(ph.t * ph.dy), (float)(ph.t * ph.dz));
+        cidxp = 16 * (ph.idx + 1);
+        if (a.pix && in_canvas && slice == 0) {
+            a.pix[2 * (size_t)pc] = make_float4(cP0.x, cP0.y, cP0.z, cd0.x);
+            a.pix[2 * (size_t)pc + 1] = make_float4(cd0.y, cd0.z, __int_as_float(cidxp), 0.f);
+        }
+    }
     f3 ccol = mk3(1.f, 1.f, 1.f);
-    int cidxp = 16 * (ph.idx + 1); float ce = 0.f;
-    bool traced = in_canvas && ph.idx >= 0 && B >= 2;     // else every sample is black (src/Lib.hs:68,72)
+    float ce = 0.f;
+    bool traced = in_canvas && cidxp != 0 && B >= 2;      // else every sample is black (src/Lib.hs:68,72)
     __syncthreads();                                       // s_mat is staged
-    if (in_canvas && ph.idx >= 0) {
+    if (in_canvas && cidxp != 0) {
         const float4 m0 = matp(cidxp, 0);
         ce = m0.w; ccol = mk3(m0.x, m0.y, m0.z);
         if (ce > 0.f) {                                    // the primary ray sees a light (src/Lib.hs:74)

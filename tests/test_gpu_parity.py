@@ -298,7 +298,7 @@ def test_work_sharing_renders_the_same_paths(pa, H, W, spp, bounces):
             chunked.trace(n)
         a, b, c = steal.read_sum_f32(), strict.read_sum_f32(), chunked.read_sum_f32()
         assert steal.segments == strict.segments
-        assert chunked.segments == strict.segments + 2 * H * W
+        assert chunked.segments == strict.segments      # the primary hits are searched once and kept for later launches
     assert np.allclose(a, b, rtol=2e-6, atol=1e-6)
     assert np.allclose(c, b, rtol=2e-6, atol=1e-6)
     assert b.sum() > 0
@@ -325,12 +325,40 @@ def test_sample_slices_of_a_large_launch(pa, H, W, spp):
         a, b, c, d = sliced.read_sum_f32(), strict.read_sum_f32(), small.read_sum_f32(), cont.read_sum_f32()
         launches = -(-spp // 200)
         assert sliced.segments == strict.segments
-        assert small.segments == strict.segments + (launches - 1) * H * W
-        assert cont.segments == strict.segments + H * W
+        assert launches > 1
+        assert small.segments == strict.segments         # (the primary hits are searched by the first launch only)
+        assert cont.segments == strict.segments
         assert sliced.samples_done == spp
     for x in (a, c, d):
         assert np.allclose(x, b, rtol=4e-6, atol=1e-5)
     assert b.sum() > 0
+
+
+def test_kept_primary_hits_follow_the_scene(pa):
+    """The fp64 primary hits are searched by the first pt_trace and kept for later
+    launches of the same camera and scene; pt_scene_upload must drop them, and
+    pt_reset must not need them redone."""
+    H, W, spp = 48, 40, 9
+    P = pa.Params(H, W, 120.0, spp, 6)
+    other = [pa.Object((1, 1, 1), 0, False, pa.InfinitePlane((0, 0, 300), (0, 0, -1)), "wall"),
+             pa.Object((1, 1, 1), 3.0, True, pa.Disk((0.0, 0.0, -5.0), (0.0, 0.0, 1.0), 60.0), "lamp"),
+             pa.Object((0.8, 0.3, 0.3), 0, False, pa.Disk((10.0, -10.0, 150.0), (0.2, 0.1, -1.0), 70.0), "disk")]
+    with pa.Renderer(P, seed=5) as r, pa.Renderer(P, other, seed=5) as want_other, pa.Renderer(P, seed=5) as want_default:
+        r.trace(spp)                                     # default scene: its primary hits are now kept
+        first = r.read_sum_f32()
+        r.upload(other)
+        r.reset()
+        r.trace(4); r.trace(spp - 4)                     # second launch reads what the first one of THIS scene kept
+        want_other.trace(spp)
+        assert np.allclose(r.read_sum_f32(), want_other.read_sum_f32(), rtol=2e-6, atol=1e-6)
+        assert r.segments == want_other.segments
+        r.upload(pa.objects)
+        r.reset()
+        r.trace(spp)
+        want_default.trace(spp)
+        assert np.array_equal(r.read_sum_f32(), want_default.read_sum_f32()) and np.array_equal(first, want_default.read_sum_f32())
+        assert r.segments == want_default.segments
+    assert first.sum() > 0
 
 
 def test_traces_generator(pa):
@@ -514,7 +542,8 @@ def test_reset_is_lazy_but_exact(pa):
         a.trace(5)
         fresh.trace(5)
         assert np.array_equal(a.read_sum_f32(), fresh.read_sum_f32())
-        assert a.segments == fresh.segments and a.samples_done == 5
+        # (the primary hits of this camera and scene are kept across pt_reset: H*W searches are not repeated)
+        assert a.segments == fresh.segments - 40 * 52 and a.samples_done == 5
         for _ in range(3):                                 # repeated resets, nothing in between
             a.reset()
         assert not a.read_sum_f32().any() and a.segments == 0
