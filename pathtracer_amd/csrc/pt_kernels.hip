@@ -29,6 +29,7 @@
 //   copy staged once per workgroup.
 #include "pt_internal.hpp"
 
+#include <cstdlib>
 #include <type_traits>
 
 namespace pt {
@@ -640,6 +641,269 @@ __global__ __launch_bounds__(NS == -2 ? 64 : TRACE_BLOCK) void trace_steal_kerne
 }
 
 // ---------------------------------------------------------------------------
+// trace kernel for scenes searched through the spatial index (pt_bvh.hpp).
+// Walks of different rays differ widely in length (10,000 disks: 51 node visits
+// on average, 116 for the slowest lane of a wave), and a loop that runs one
+// whole closest-hit search per trip (trace_steal_kernel<-2>) keeps every lane
+// waiting for the slowest: 22 % of the lanes were active.  Here a lane's search
+// is a resumable state (node, stack depth, best hit so far) and the wave
+// alternates between two steps:
+//   walk  : every lane that is searching visits up to BVH_ROUND_VISITS nodes and
+//           at most one leaf;
+//   shade : the lanes whose search has finished (as soon as BVH_SHADE_LANES of
+//           them wait, or nobody is searching) take the radiance, bounce or
+//           restart -- drawing the next sample from the wave's pool exactly as
+//           trace_steal_kernel's sharing phase does -- and start their next
+//           search at once.
+// The arithmetic of a search and of a bounce is that of the other kernels, so the
+// paths, the hits and pt_segments are the same; only WHEN a lane does what
+// changes (and with it the fp32 summation order of a pixel's samples).
+// ---------------------------------------------------------------------------
+constexpr int BVH_BLOCK = 64;
+#ifndef PT_BVH_ROUND_VISITS
+#define PT_BVH_ROUND_VISITS 12
+#endif
+#ifndef PT_BVH_SHADE_LANES
+#define PT_BVH_SHADE_LANES 24
+#endif
+
+template <bool SPEC>
+__global__ __launch_bounds__(BVH_BLOCK) void trace_bvh_kernel(TraceArgs a)
+{
+    constexpr int BLOCK = BVH_BLOCK;
+    int *const stack = reinterpret_cast<int *>(s_tile) + threadIdx.x;   // [entry][lane], sized by the launcher
+    __shared__ uint32_t s_next[BLOCK];          // per pixel: next sample (launch-local index) not started
+    __shared__ float4   s_pix[BLOCK * 3];       // per pixel: P0, d0, colour0, idx0, e0
+    __shared__ float    s_acc[BLOCK * 3];       // per pixel: radiance gathered for it by other lanes
+    auto mat = [&](int k, int f) -> float4 { return a.mat[k * 4 + f]; };
+
+    const int tid = threadIdx.x;
+    const int npix = a.height * a.width;
+    const int pixel0 = blockIdx.x * BLOCK;
+    const bool in_canvas = pixel0 + tid < npix;
+    const int pc = in_canvas ? pixel0 + tid : 0;
+    const int pi = pc / a.width, pj = pc - pi * a.width;
+    const uint32_t n = (uint32_t)a.n_samples;
+    const int B = a.max_bounces;
+
+    unsigned long long segs = in_canvas ? 1 : 0;          // the fp64 primary search below
+    f3 acc = mk3(0.f, 0.f, 0.f);
+    if (in_canvas && !a.fresh) acc = mk3(a.canvas[3 * (size_t)pc + 0], a.canvas[3 * (size_t)pc + 1], a.canvas[3 * (size_t)pc + 2]);
+
+    // primary segment, once per pixel, fp64 (src/Lib.hs:41-51, :81-98)
+    const PrimaryHit ph = primary_hit(a, pi, pj, stack, BLOCK);
+    f3 cd0 = mk3((float)ph.dx, (float)ph.dy, (float)ph.dz);
+    f3 cP0 = mk3((float)(ph.t * ph.dx), (float)(ph.t * ph.dy), (float)(ph.t * ph.dz));
+    f3 ccol = mk3(1.f, 1.f, 1.f);
+    int cidx = ph.idx; float ce = 0.f;
+    bool traced = in_canvas && cidx >= 0 && B >= 2;       // else every sample is black (src/Lib.hs:68,72)
+    if (in_canvas && cidx >= 0) {
+        const float4 m0 = mat(cidx, 0);
+        ce = m0.w; ccol = mk3(m0.x, m0.y, m0.z);
+        if (ce > 0.f) {                                    // the primary ray sees a light (src/Lib.hs:74)
+            for (uint32_t s = 0; s < n; ++s) { acc.x += ce; acc.y += ce; acc.z += ce; }
+            traced = false;
+        }
+    }
+    s_pix[tid * 3 + 0] = make_float4(cP0.x, cP0.y, cP0.z, cd0.x);
+    s_pix[tid * 3 + 1] = make_float4(cd0.y, cd0.z, ccol.x, ccol.y);
+    s_pix[tid * 3 + 2] = make_float4(ccol.z, __int_as_float(cidx), ce, 0.f);
+    s_next[tid] = traced && n > 0 ? 1u : n;                // a traced pixel's own lane starts on its sample 0
+    s_acc[tid * 3 + 0] = 0.f; s_acc[tid * 3 + 1] = 0.f; s_acc[tid * 3 + 2] = 0.f;
+    __syncthreads();
+
+    uint64_t pre = (uint64_t)0xD256D193u * (uint64_t)(uint32_t)pc;
+    f3 o = cP0, d = cd0, thr = ccol;
+    int last = cidx, b = 1;
+    uint32_t gs = a.sample_begin;
+    int cur = tid;                                         // the pixel (workgroup-relative) this lane works on
+    const PhiloxRegs pregs = philox_regs(a.seed);
+    auto scatter = [&](int idx, float e, f3 din, int bounce, f3 at) -> f3 {
+        uint32_t r0, r1;
+        philox2x32_10_pre_v((uint32_t)(pre >> 32), (uint32_t)pre, (gs << 6) | (uint32_t)bounce, pregs, r0, r1);
+        if constexpr (SPEC) {
+            const float4 m3 = mat(idx, 3);
+            f3 nrm = mk3(m3.y, m3.z, m3.w);
+            const bool sphere = m3.x != m3.x;              // NaN marks the Sphere extension: normal at the hit point
+            if (sphere) {
+                const float4 m1 = mat(idx, 1);
+                nrm = mk3((at.x - m1.x) * m1.w, (at.y - m1.y) * m1.w, (at.z - m1.z) * m1.w);
+            }
+            if (e < 0.f)                                   // _reflective (src/Lib.hs:110)
+                return scatter_specular(din, nrm, u_theta(r0), u_phi(r1), NOISE_REV);
+            if (sphere) return scatter_diffuse_about(nrm, r0, r1);
+        }
+        return scatter_diffuse_bits(mat(idx, 1), mat(idx, 2), mat(idx, 3).x, r0, r1);   // src/Lib.hs:111
+    };
+
+    // ---- the resumable closest-hit search (closest<-2>'s arithmetic) ----------
+    const float4 *__restrict__ g = a.bvh_geom;
+    const float4 *__restrict__ nodes = a.bvh_nodes;
+    int wn = -1, wsp = 0, wbest = -1;
+    uint32_t wkey = KEY_LIMIT, neg = 0;
+    float wbt = __builtin_inff(), ix = 0.f, iy = 0.f, iz = 0.f;
+    auto test = [&](float4 g0, float4 g1, float4 g2, bool on) {
+        const int k = __float_as_int(g2.w);
+        const float num = fmaf(-o.z, g0.z, fmaf(-o.y, g0.y, fmaf(-o.x, g0.x, g0.w)));
+        const float den = fmaf(d.z, g1.z, fmaf(d.y, g1.y, d.x * g1.x));
+        float t = num * __builtin_amdgcn_rcpf(den);
+        const float dx = fmaf(t, d.x, o.x) - g2.x;             // Disk (src/Object.hs:165-171); a plane has r2 = +Inf
+        const float dy = fmaf(t, d.y, o.y) - g2.y;
+        const float dz = fmaf(t, d.z, o.z) - g2.z;
+        bool inside = inside_form<SPEC>(a.rect, k, g1.w, dx, dy, dz) || (g1.w == __builtin_inff());
+        if constexpr (SPEC) {
+            const float ts = sphere_t(mk3(g2.x, g2.y, g2.z), -g1.w, o, d);
+            t = (g1.w < 0.0f) ? ts : t;
+            inside = inside || (g1.w < 0.0f);
+        }
+        uint32_t key = __float_as_uint(t) - 1u;
+        key = (k == last || !on || !inside) ? KEY_INVALID : key;     // _lastStruck (src/Lib.hs:86-90)
+        const bool better = (key < wkey) | ((key == wkey) & (key < KEY_LIMIT) & (k < wbest));
+        wbest = better ? k : wbest;
+        wkey = better ? key : wkey;
+        wbt = better ? t : wbt;
+    };
+    auto begin_search = [&]() {
+        wbest = -1; wkey = KEY_LIMIT; wbt = __builtin_inff();
+        for (int u = 0; u < a.n_unbounded; ++u) test(g[3 * u], g[3 * u + 1], g[3 * u + 2], true);
+        ix = __builtin_amdgcn_rcpf(d.x); iy = __builtin_amdgcn_rcpf(d.y); iz = __builtin_amdgcn_rcpf(d.z);
+        neg = (d.x < 0.f ? 1u : 0u) | (d.y < 0.f ? 2u : 0u) | (d.z < 0.f ? 4u : 0u);
+        wn = 0; wsp = 0;
+    };
+    auto pop = [&]() -> int {
+        if (wsp == 0) return -1;
+        wsp -= 1;
+        return stack[wsp * BLOCK];
+    };
+
+    bool live = traced && n > 0;                           // has a path in flight
+    bool walking = false, ready = !live;                   // pathless lanes ask the pool for work at the first shade step
+    if (live) { d = scatter(cidx, ce, cd0, 0, cP0); begin_search(); walking = true; }
+    bool dry = false;                                      // wave-uniform: no pixel has an unstarted sample
+
+    for (;;) {
+        const unsigned long long wm = __ballot(walking), rm = __ballot(ready);
+        if (wm == 0ull && rm == 0ull) break;
+        if (rm != 0ull && (wm == 0ull || __popcll(rm) >= PT_BVH_SHADE_LANES)) {
+            // ---- shade: the lanes whose search has finished ----------------------
+            int k = -1; float t = 0.f;
+            float4 m0 = make_float4(0.f, 0.f, 0.f, 0.f);
+            bool terminal = false;
+            if (ready && live) {
+                k = wbest;
+                key_result(k, wkey, t);
+                segs += 1;
+                const bool hit = k >= 0;
+                m0 = mat(hit ? k : 0, 0);
+                // miss (src/Lib.hs:72), light (:74) or the depth cap (:68) end the path
+                terminal = !hit || (m0.w > 0.f) || (b + 1 >= B);
+                const float E = hit ? fmaxf(m0.w, 0.f) : 0.f;                // emittance * pixel (src/Lib.hs:74)
+                acc.x = fmaf(E, thr.x, acc.x);
+                acc.y = fmaf(E, thr.y, acc.y);
+                acc.z = fmaf(E, thr.z, acc.z);
+            }
+            // the next sample: of my current pixel, else of any pixel of the wave that has one left
+            uint32_t sn = 0;
+            if (ready && live && terminal) sn = atomicAdd(&s_next[cur], 1u);
+            const bool want = ready && (terminal || !live);
+            bool needy = want && !(live && terminal && sn < n);
+            while (!dry && __ballot(needy) != 0ull) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                const bool has = __hip_atomic_load(&s_next[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < n;
+                const unsigned long long avail = __ballot(has);
+                if (avail == 0ull) { dry = true; break; }
+                const int v = __ffsll((long long)avail) - 1;     // wave-uniform choice of pixel to help
+                if (needy) {
+                    sn = atomicAdd(&s_next[v], 1u);
+                    if (sn < n) {
+                        if (v != cur) {                    // hand over what was gathered, adopt pixel v
+                            atomicAdd(&s_acc[cur * 3 + 0], acc.x);
+                            atomicAdd(&s_acc[cur * 3 + 1], acc.y);
+                            atomicAdd(&s_acc[cur * 3 + 2], acc.z);
+                            acc = mk3(0.f, 0.f, 0.f);
+                            cur = v;
+                            const float4 p0 = s_pix[v * 3 + 0], p1 = s_pix[v * 3 + 1], p2 = s_pix[v * 3 + 2];
+                            cP0 = mk3(p0.x, p0.y, p0.z); cd0 = mk3(p0.w, p1.x, p1.y); ccol = mk3(p1.z, p1.w, p2.x);
+                            cidx = __float_as_int(p2.y); ce = p2.z;
+                            pre = (uint64_t)0xD256D193u * (uint64_t)(uint32_t)(pixel0 + v);
+                        }
+                        needy = false;
+                    }
+                }
+            }
+            if (ready) {
+                if (want && needy) {                       // the pool is dry: this lane is done
+                    live = false; ready = false;
+                } else {
+                    const bool restart = want;             // a new sample from the (current) pixel's primary hit
+                    if (restart) gs = a.sample_begin + sn * a.sample_stride;
+                    const int   idx = restart ? cidx : k;
+                    const float e   = restart ? ce : m0.w;
+                    const f3    din = restart ? cd0 : d;
+                    const int   bn  = restart ? 0 : b;
+                    const f3 hp = mk3(restart ? cP0.x : fmaf(t, d.x, o.x),     // march (src/Object.hs:151-153)
+                                      restart ? cP0.y : fmaf(t, d.y, o.y),
+                                      restart ? cP0.z : fmaf(t, d.z, o.z));
+                    thr = mk3(restart ? ccol.x : thr.x * m0.x,                   // pixel * color (src/Lib.hs:79)
+                              restart ? ccol.y : thr.y * m0.y,
+                              restart ? ccol.z : thr.z * m0.z);
+                    d = scatter(idx, e, din, bn, hp);
+                    o = hp; last = idx; b = bn + 1;
+                    live = true; ready = false; walking = true;
+                    begin_search();
+                }
+            }
+        } else {
+            // ---- walk: up to PT_BVH_ROUND_VISITS nodes and one leaf per searching lane
+            if (walking) {
+                int code = -1, steps = 0;
+                while (wn >= 0 && steps < PT_BVH_ROUND_VISITS) {
+                    const float4 nd = nodes[wn];
+                    steps += 1;
+                    if (!slab_hit(nd, o.x, o.y, o.z, ix, iy, iz, wbt)) { wn = pop(); continue; }
+                    const int c = __float_as_int(nd.w);
+                    if (c >= 0) { code = c; break; }
+                    const int cc = -(c + 1), right = cc >> 2, left = wn + 1;
+                    const bool right_first = (neg >> (cc & 3)) & 1u;
+                    stack[wsp * BLOCK] = right_first ? left : right;
+                    wsp += 1;
+                    wn = right_first ? right : left;
+                }
+                if (code >= 0) {
+                    const int first = code >> 3, cnt = (code & 7) + 1;
+#pragma unroll 1
+                    for (int h = 0; h < BVH_LEAF_SLOTS; h += 2) {
+                        float4 r[2][3];
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            r[q][0] = g[3 * (first + h + q)]; r[q][1] = g[3 * (first + h + q) + 1]; r[q][2] = g[3 * (first + h + q) + 2];
+                        }
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) test(r[q][0], r[q][1], r[q][2], h + q < cnt);
+                        if (h + 2 >= cnt) break;
+                    }
+                    wn = pop();
+                }
+                if (wn < 0) { walking = false; ready = true; }
+            }
+        }
+    }
+
+    atomicAdd(&s_acc[cur * 3 + 0], acc.x);
+    atomicAdd(&s_acc[cur * 3 + 1], acc.y);
+    atomicAdd(&s_acc[cur * 3 + 2], acc.z);
+    __syncthreads();
+    if (in_canvas) {
+        a.canvas[3 * (size_t)pc + 0] = s_acc[tid * 3 + 0];
+        a.canvas[3 * (size_t)pc + 1] = s_acc[tid * 3 + 1];
+        a.canvas[3 * (size_t)pc + 2] = s_acc[tid * 3 + 2];
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) segs += __shfl_down(segs, off, 64);
+    if ((tid & 63) == 0 && segs) atomicAdd(seg_lane(a.segments), segs);
+}
+
+// ---------------------------------------------------------------------------
 // trace kernel for small scenes (object list in the kernel arguments), the
 // default for <= 8 objects.  Same two phases and the same work sharing as
 // trace_steal_kernel; what differs is the instruction diet, shaped by the issue
@@ -1098,6 +1362,11 @@ static hipError_t launch_trace_ns(TraceArgs a, const float4 *geom_host, bool reu
             constexpr int SB = NS == -2 ? 64 : TRACE_BLOCK;
             const dim3 tgrid((npix + SB - 1) / SB), tblock(SB);
             const size_t ssm = NS == -2 ? (size_t)(a.bvh_depth + 1) * SB * sizeof(int) : 0;
+            if (NS == -2 && !getenv("PT_BVH_LOCKSTEP")) {      // (PT_BVH_LOCKSTEP: the one-search-per-trip loop, for A/B)
+                if (spec) hipLaunchKernelGGL((trace_bvh_kernel<true>), tgrid, tblock, ssm, s, a);
+                else      hipLaunchKernelGGL((trace_bvh_kernel<false>), tgrid, tblock, ssm, s, a);
+                return hipGetLastError();
+            }
             if (spec) hipLaunchKernelGGL((trace_steal_kernel<NS, true>), tgrid, tblock, ssm, s, a, sg, a.geom);
             else      hipLaunchKernelGGL((trace_steal_kernel<NS, false>), tgrid, tblock, ssm, s, a, sg, a.geom);
             return hipGetLastError();

@@ -555,8 +555,11 @@ def test_reset_is_lazy_but_exact(pa):
 @pytest.mark.parametrize("n,seed,bounces", [(17, 21, 6), (40, 7, 6), (300, 8, 5), (1025, 10, 4), (2500, 11, 6)])
 def test_spatial_index_finds_the_linear_scans_object(pa, n, seed, bounces, steal_flag):
     """The BVH only prunes (pt_bvh.hpp): with and without it the same object is
-    struck on every segment, so canvases, executed searches and fp64 primary
-    hits are equal bit for bit (closestObjectTo, src/Lib.hs:81-98, is the scan)."""
+    struck on every segment, so executed searches and fp64 primary hits are equal,
+    and canvases are equal bit for bit in the strict sample order
+    (PT_FLAG_NO_STEAL) and up to the fp32 summation order of a pixel's samples
+    otherwise -- the indexed kernel hands samples to idle lanes at other moments
+    than the scan does (closestObjectTo, src/Lib.hs:81-98, is the scan)."""
     objs = pa.random_disk_scene(n, seed)
     H, W, spp = 72, 56, 5
     out = []
@@ -567,7 +570,7 @@ def test_spatial_index_finds_the_linear_scans_object(pa, n, seed, bounces, steal
             out.append((r.read_sum_f32(), r.segments, r.primary_hits()))
     (a, sa, pa_), (b, sb, pb) = out
     assert sa == sb
-    assert np.array_equal(a, b)
+    assert np.array_equal(a, b) if steal_flag else np.allclose(a, b, rtol=2e-6, atol=1e-6)
     for x, y in zip(pa_, pb):
         assert np.array_equal(x, y)
     if n >= 300:                                           # 2 % of the objects are lights
@@ -586,11 +589,12 @@ def test_spatial_index_with_coincident_and_degenerate_disks(pa):
              pa.Object((1, 1, 1), 0.0, False, pa.Disk((20.0, 0.0, 300.0), (0.0, 0.0, 0.0), 30.0), "n = 0")]
     H, W, spp = 64, 64, 4
     res = []
-    for flags in (0, pa.PT_FLAG_NO_BVH):
+    for flags in (0, pa.PT_FLAG_NO_BVH, pa.PT_FLAG_NO_STEAL, pa.PT_FLAG_NO_STEAL | pa.PT_FLAG_NO_BVH):
         with pa.Renderer(pa.Params(H, W, 60.0, spp, 6), objs, seed=9, flags=flags) as r:
             r.trace(spp)
             res.append((r.read_sum_f32(), r.segments, r.primary_hits()[0]))
-    assert res[0][1] == res[1][1]
-    assert np.array_equal(res[0][0], res[1][0])
-    assert np.array_equal(res[0][2], res[1][2])
+    assert res[0][1] == res[1][1] == res[2][1] == res[3][1]
+    assert np.array_equal(res[2][0], res[3][0])             # strict sample order: bit for bit
+    assert np.allclose(res[0][0], res[1][0], rtol=2e-6, atol=1e-6) and np.allclose(res[0][0], res[2][0], rtol=2e-6, atol=1e-6)
+    assert np.array_equal(res[0][2], res[1][2]) and np.array_equal(res[2][2], res[3][2])
     assert not np.isin(res[0][2], [60, 61, 62]).any()       # a duplicate never wins over object 5
