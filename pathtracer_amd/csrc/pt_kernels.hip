@@ -664,7 +664,7 @@ constexpr int BVH_BLOCK = 64;
 #define PT_BVH_ROUND_VISITS 12
 #endif
 #ifndef PT_BVH_SHADE_LANES
-#define PT_BVH_SHADE_LANES 24
+#define PT_BVH_SHADE_LANES 12
 #endif
 
 template <bool SPEC>
