@@ -717,10 +717,10 @@ __global__ __launch_bounds__(BVH_BLOCK) void trace_bvh_kernel(TraceArgs a)
     int last = cidx, b = 1;
     uint32_t gs = a.sample_begin;
     int cur = tid;                                         // the pixel (workgroup-relative) this lane works on
-    const PhiloxRegs pregs = philox_regs(a.seed);
     auto scatter = [&](int idx, float e, f3 din, int bounce, f3 at) -> f3 {
         uint32_t r0, r1;
-        philox2x32_10_pre_v((uint32_t)(pre >> 32), (uint32_t)pre, (gs << 6) | (uint32_t)bounce, pregs, r0, r1);
+        // (round keys as scalar operands: this kernel is bound by its gathers and by registers, not by the SGPR port)
+        philox2x32_10_pre((uint32_t)(pre >> 32), (uint32_t)pre, (gs << 6) | (uint32_t)bounce, a.seed, r0, r1);
         if constexpr (SPEC) {
             const float4 m3 = mat(idx, 3);
             f3 nrm = mk3(m3.y, m3.z, m3.w);
@@ -822,9 +822,6 @@ __global__ __launch_bounds__(BVH_BLOCK) void trace_bvh_kernel(TraceArgs a)
                             atomicAdd(&s_acc[cur * 3 + 2], acc.z);
                             acc = mk3(0.f, 0.f, 0.f);
                             cur = v;
-                            const float4 p0 = s_pix[v * 3 + 0], p1 = s_pix[v * 3 + 1], p2 = s_pix[v * 3 + 2];
-                            cP0 = mk3(p0.x, p0.y, p0.z); cd0 = mk3(p0.w, p1.x, p1.y); ccol = mk3(p1.z, p1.w, p2.x);
-                            cidx = __float_as_int(p2.y); ce = p2.z;
                             pre = (uint64_t)0xD256D193u * (uint64_t)(uint32_t)(pixel0 + v);
                         }
                         needy = false;
@@ -835,18 +832,20 @@ __global__ __launch_bounds__(BVH_BLOCK) void trace_bvh_kernel(TraceArgs a)
                 if (want && needy) {                       // the pool is dry: this lane is done
                     live = false; ready = false;
                 } else {
-                    const bool restart = want;             // a new sample from the (current) pixel's primary hit
+                    const bool restart = want;             // a new sample from the (current) pixel's primary hit,
                     if (restart) gs = a.sample_begin + sn * a.sample_stride;
-                    const int   idx = restart ? cidx : k;
-                    const float e   = restart ? ce : m0.w;
-                    const f3    din = restart ? cd0 : d;
+                    // whose constants live in LDS, not in registers: the walk needs the registers (occupancy)
+                    const float4 p0 = s_pix[cur * 3 + 0], p1 = s_pix[cur * 3 + 1], p2 = s_pix[cur * 3 + 2];
+                    const int   idx = restart ? __float_as_int(p2.y) : k;
+                    const float e   = restart ? p2.z : m0.w;
+                    const f3    din = restart ? mk3(p0.w, p1.x, p1.y) : d;
                     const int   bn  = restart ? 0 : b;
-                    const f3 hp = mk3(restart ? cP0.x : fmaf(t, d.x, o.x),     // march (src/Object.hs:151-153)
-                                      restart ? cP0.y : fmaf(t, d.y, o.y),
-                                      restart ? cP0.z : fmaf(t, d.z, o.z));
-                    thr = mk3(restart ? ccol.x : thr.x * m0.x,                   // pixel * color (src/Lib.hs:79)
-                              restart ? ccol.y : thr.y * m0.y,
-                              restart ? ccol.z : thr.z * m0.z);
+                    const f3 hp = mk3(restart ? p0.x : fmaf(t, d.x, o.x),      // march (src/Object.hs:151-153)
+                                      restart ? p0.y : fmaf(t, d.y, o.y),
+                                      restart ? p0.z : fmaf(t, d.z, o.z));
+                    thr = mk3(restart ? p1.z : thr.x * m0.x,                     // pixel * color (src/Lib.hs:79)
+                              restart ? p1.w : thr.y * m0.y,
+                              restart ? p2.x : thr.z * m0.z);
                     d = scatter(idx, e, din, bn, hp);
                     o = hp; last = idx; b = bn + 1;
                     live = true; ready = false; walking = true;
