@@ -686,7 +686,7 @@ __global__ __launch_bounds__(BVH_BLOCK) void trace_bvh_kernel(TraceArgs a)
     const uint32_t n = (uint32_t)a.n_samples;
     const int B = a.max_bounces;
 
-    unsigned long long segs = in_canvas ? 1 : 0;          // the fp64 primary search below
+    uint32_t segs = in_canvas ? 1u : 0u;                   // the fp64 primary search below (a lane runs < 2^32 searches per launch)
     f3 acc = mk3(0.f, 0.f, 0.f);
     if (in_canvas && !a.fresh) acc = mk3(a.canvas[3 * (size_t)pc + 0], a.canvas[3 * (size_t)pc + 1], a.canvas[3 * (size_t)pc + 2]);
 
@@ -709,16 +709,17 @@ __global__ __launch_bounds__(BVH_BLOCK) void trace_bvh_kernel(TraceArgs a)
     s_pix[tid * 3 + 1] = make_float4(cd0.y, cd0.z, ccol.x, ccol.y);
     s_pix[tid * 3 + 2] = make_float4(ccol.z, __int_as_float(cidx), ce, 0.f);
     s_next[tid] = traced && n > 0 ? 1u : n;                // a traced pixel's own lane starts on its sample 0
-    s_acc[tid * 3 + 0] = 0.f; s_acc[tid * 3 + 1] = 0.f; s_acc[tid * 3 + 2] = 0.f;
+    // the per-pixel sums live in LDS for the whole launch (registers are what limits the occupancy of the walk)
+    s_acc[tid * 3 + 0] = acc.x; s_acc[tid * 3 + 1] = acc.y; s_acc[tid * 3 + 2] = acc.z;
     __syncthreads();
 
-    uint64_t pre = (uint64_t)0xD256D193u * (uint64_t)(uint32_t)pc;
     f3 o = cP0, d = cd0, thr = ccol;
     int last = cidx, b = 1;
     uint32_t gs = a.sample_begin;
     int cur = tid;                                         // the pixel (workgroup-relative) this lane works on
     auto scatter = [&](int idx, float e, f3 din, int bounce, f3 at) -> f3 {
         uint32_t r0, r1;
+        const uint64_t pre = (uint64_t)0xD256D193u * (uint64_t)(uint32_t)(pixel0 + cur);   // Philox's first product
         // (round keys as scalar operands: this kernel is bound by its gathers and by registers, not by the SGPR port)
         philox2x32_10_pre((uint32_t)(pre >> 32), (uint32_t)pre, (gs << 6) | (uint32_t)bounce, a.seed, r0, r1);
         if constexpr (SPEC) {
@@ -797,10 +798,11 @@ __global__ __launch_bounds__(BVH_BLOCK) void trace_bvh_kernel(TraceArgs a)
                 m0 = mat(hit ? k : 0, 0);
                 // miss (src/Lib.hs:72), light (:74) or the depth cap (:68) end the path
                 terminal = !hit || (m0.w > 0.f) || (b + 1 >= B);
-                const float E = hit ? fmaxf(m0.w, 0.f) : 0.f;                // emittance * pixel (src/Lib.hs:74)
-                acc.x = fmaf(E, thr.x, acc.x);
-                acc.y = fmaf(E, thr.y, acc.y);
-                acc.z = fmaf(E, thr.z, acc.z);
+                if (hit && m0.w > 0.f) {                                     // emittance * pixel (src/Lib.hs:74)
+                    atomicAdd(&s_acc[cur * 3 + 0], m0.w * thr.x);
+                    atomicAdd(&s_acc[cur * 3 + 1], m0.w * thr.y);
+                    atomicAdd(&s_acc[cur * 3 + 2], m0.w * thr.z);
+                }
             }
             // the next sample: of my current pixel, else of any pixel of the wave that has one left
             uint32_t sn = 0;
@@ -816,14 +818,7 @@ __global__ __launch_bounds__(BVH_BLOCK) void trace_bvh_kernel(TraceArgs a)
                 if (needy) {
                     sn = atomicAdd(&s_next[v], 1u);
                     if (sn < n) {
-                        if (v != cur) {                    // hand over what was gathered, adopt pixel v
-                            atomicAdd(&s_acc[cur * 3 + 0], acc.x);
-                            atomicAdd(&s_acc[cur * 3 + 1], acc.y);
-                            atomicAdd(&s_acc[cur * 3 + 2], acc.z);
-                            acc = mk3(0.f, 0.f, 0.f);
-                            cur = v;
-                            pre = (uint64_t)0xD256D193u * (uint64_t)(uint32_t)(pixel0 + v);
-                        }
+                        cur = v;                           // adopt pixel v
                         needy = false;
                     }
                 }
@@ -888,18 +883,16 @@ __global__ __launch_bounds__(BVH_BLOCK) void trace_bvh_kernel(TraceArgs a)
         }
     }
 
-    atomicAdd(&s_acc[cur * 3 + 0], acc.x);
-    atomicAdd(&s_acc[cur * 3 + 1], acc.y);
-    atomicAdd(&s_acc[cur * 3 + 2], acc.z);
     __syncthreads();
     if (in_canvas) {
         a.canvas[3 * (size_t)pc + 0] = s_acc[tid * 3 + 0];
         a.canvas[3 * (size_t)pc + 1] = s_acc[tid * 3 + 1];
         a.canvas[3 * (size_t)pc + 2] = s_acc[tid * 3 + 2];
     }
+    unsigned long long wsegs = segs;
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) segs += __shfl_down(segs, off, 64);
-    if ((tid & 63) == 0 && segs) atomicAdd(seg_lane(a.segments), segs);
+    for (int off = 32; off > 0; off >>= 1) wsegs += __shfl_down(wsegs, off, 64);
+    if ((tid & 63) == 0 && wsegs) atomicAdd(seg_lane(a.segments), wsegs);
 }
 
 // ---------------------------------------------------------------------------
