@@ -1156,7 +1156,7 @@ __global__ __launch_bounds__(STATIC_BLOCK) void trace_static_kernel(TraceArgs a,
             if (!decltype(all_alive)::value) tm = __builtin_amdgcn_ballot_w64(terminal);   // phase 2's draw rewrites it
         }
         int idxp; float e; f3 din, hp;
-        if constexpr (MASKS && !SPEC) {
+        if constexpr (MASKS) {
             // The continuing path's values for every lane, then the restart values moved in under the lane
             // mask: eight v_mov_b32 (plain issue class) where selects would be eight v_cndmask_b32
             // (second-port class, the binding one in this loop; tools/ubench_issue.hip)
@@ -1178,6 +1178,16 @@ __global__ __launch_bounds__(STATIC_BLOCK) void trace_static_kernel(TraceArgs a,
                   [tz] "+v"(thr.z), [c] "+v"(c1), [sv] "=&s"(saved)
                 : [m] "s"(tm), [ci] "v"(cidxp), [px] "v"(cP0.x), [py] "v"(cP0.y), [pz] "v"(cP0.z), [cx] "v"(ccol.x),
                   [cy] "v"(ccol.y), [cz] "v"(ccol.z), [cr] "v"(c1r));
+            if constexpr (SPEC) {                          // the specular bounce also reads the tag and the incoming direction
+                asm("s_and_saveexec_b64 %[sv], %[m]\n\t"
+                    "v_mov_b32 %[e], %[ce]\n\t"
+                    "v_mov_b32 %[dx], %[qx]\n\t"
+                    "v_mov_b32 %[dy], %[qy]\n\t"
+                    "v_mov_b32 %[dz], %[qz]\n\t"
+                    "s_mov_b64 exec, %[sv]"
+                    : [e] "+v"(e), [dx] "+v"(din.x), [dy] "+v"(din.y), [dz] "+v"(din.z), [sv] "=&s"(saved)
+                    : [m] "s"(tm), [ce] "v"(ce), [qx] "v"(cd0.x), [qy] "v"(cd0.y), [qz] "v"(cd0.z));
+            }
         } else {
             c1 = terminal ? c1r : c1;
             idxp = terminal ? cidxp : kp;
