@@ -4,8 +4,15 @@
 //                         bounceRay (src/Lib.hs:58-132) for n samples per pixel,
 //                         scenes of <= 8 objects (object list in the kernel
 //                         arguments): THE hot kernel, the one bench.py times.
-//   trace_steal_kernel  : the same loop for larger scenes, over the scalar-
-//                         streamed object list (NS = 0) or the BVH (NS = -2).
+//                         Large launches run as two sample slices of one grid;
+//                         slice_sum_kernel adds the second slice's plane.
+//   trace_bvh_kernel    : larger scenes searched through the spatial index:
+//                         resumable per-lane searches, the wave alternates walk
+//                         and shade steps.
+//   trace_steal_kernel  : the same loop as trace_static_kernel over the scalar-
+//                         streamed object list (NS = 0: PT_FLAG_NO_BVH, or too
+//                         few finite forms for an index), or one whole BVH
+//                         search per trip (NS = -2, kept for A/B).
 //   trace_kernel        : the strict variant (PT_FLAG_NO_STEAL /
 //                         NO_PRIMARY_REUSE / LDS_TILES): a pixel's samples are
 //                         summed strictly in order by its own lane.
