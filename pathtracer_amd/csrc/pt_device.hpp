@@ -401,7 +401,7 @@ __device__ __forceinline__ bool slab_hit(float4 nd, float ox, float oy, float oz
     return tn <= tf;
 }
 
-constexpr int BVH_LEAF_SLOTS = 8;         // = BVH_LEAF_MAX of pt_bvh.hpp
+constexpr int BVH_LEAF_SLOTS = 8;         // >= BVH_LEAF_MAX of pt_bvh.hpp (a leaf's count has 3 bits)
 
 // Near-child-first walk.  `stack` is this lane's column of an LDS array laid out
 // [entry][lane] (stride = lanes per workgroup): conflict-free, no scratch memory.
