@@ -396,6 +396,28 @@ def test_sample_split_union(pa):
 
 
 # ------------------------------------------------------------- output --------
+def test_sample_split_union_with_sliced_launches(pa):
+    """The same union when every shard's launch is large enough to run as two
+    sample slices (>= 256 samples) and strides its global sample indices: three
+    shards of 300 against one context's 900 samples."""
+    H, W, G, per = 32, 48, 3, 300
+    P = pa.Params(H, W, 500.0, G * per, 8)
+    with pa.Renderer(P, seed=11) as full:
+        full.trace(G * per)
+        want = full.read_sum()
+        segs = full.segments
+    total = np.zeros_like(want)
+    tsegs = 0
+    for g in range(G):
+        with pa.Renderer(P, seed=11, sample_offset=g, sample_stride=G) as r:
+            r.trace(per)
+            total += r.read_sum()
+            tsegs += r.segments
+    assert tsegs == segs + (G - 1) * H * W                # every shard searches its primary hits once
+    assert np.allclose(total, want, rtol=1e-5, atol=1e-5)
+    assert want.sum() > 0
+
+
 def test_rgb8_reference_mode_bit_exact(pa):
     """repa3ToImage + listToPixelRGB8: round-half-even(255*x), wrap mod 256,
     transposed layout (j*H + i)*3 + k -- compared byte for byte."""
