@@ -1014,7 +1014,7 @@ __global__ __launch_bounds__(STATIC_BLOCK) void trace_static_kernel(TraceArgs a,
     constexpr int R = NS + 1;                       // material records per field: miss + NS objects
     __shared__ float4   s_mat[4 * R];               // field f of object k at [f*R + k + 1]; [f*R] = miss
     __shared__ uint32_t s_next[BLOCK];              // per pixel: next global sample index not started
-    __shared__ float4   s_pix[BLOCK * 3];           // per pixel: P0, d0, colour0, idx0, e0
+    __shared__ float4   s_pix[BLOCK * 3];           // per pixel: (P0, record offset), (colour0, e0), (d0, -)
     __shared__ float    s_acc[BLOCK * 3];           // per pixel: radiance gathered in phase 2
     __shared__ unsigned long long s_segs;           // the workgroup's segment count
     const int tid = threadIdx.x;
@@ -1093,9 +1093,12 @@ __global__ __launch_bounds__(STATIC_BLOCK) void trace_static_kernel(TraceArgs a,
             traced = false;
         }
     }
-    s_pix[tid * 3 + 0] = make_float4(cP0.x, cP0.y, cP0.z, cd0.x);
-    s_pix[tid * 3 + 1] = make_float4(cd0.y, cd0.z, ccol.x, ccol.y);
-    s_pix[tid * 3 + 2] = make_float4(ccol.z, __int_as_float(cidxp), ce, 0.f);
+    s_pix[tid * 3 + 0] = make_float4(cP0.x, cP0.y, cP0.z, __int_as_float(cidxp));
+    s_pix[tid * 3 + 1] = make_float4(ccol.x, ccol.y, ccol.z, ce);
+    s_pix[tid * 3 + 2] = make_float4(cd0.x, cd0.y, cd0.z, 0.f);
+    // LDS byte address of the current pixel's restart record (MASKS: read under exec at every restart, so that
+    // the seven constants do not occupy registers through the loop -- 8 waves per SIMD instead of 7)
+    uint32_t raddr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)&s_pix[tid * 3];
 
     uint64_t pre = (uint64_t)0xD256D193u * (uint64_t)(uint32_t)pc;
     f3 o = cP0, d = cd0, thr = ccol;
@@ -1164,37 +1167,38 @@ __global__ __launch_bounds__(STATIC_BLOCK) void trace_static_kernel(TraceArgs a,
         }
         int idxp; float e; f3 din, hp;
         if constexpr (MASKS) {
-            // The continuing path's values for every lane, then the restart values moved in under the lane
-            // mask: eight v_mov_b32 (plain issue class) where selects would be eight v_cndmask_b32
-            // (second-port class, the binding one in this loop; tools/ubench_issue.hip)
-            idxp = kp; e = m0.w; din = d;
-            hp = mk3(fmaf(t, d.x, o.x), fmaf(t, d.y, o.y), fmaf(t, d.z, o.z));    // march (src/Object.hs:151-153)
-            thr = mk3(thr.x * m0.x, thr.y * m0.y, thr.z * m0.z);                  // pixel * color (src/Lib.hs:79)
+            // The continuing path's values for every lane, then the restart values read in under the lane
+            // mask from the pixel's LDS record: two ds_read_b128 and one v_mov_b32 where selects would be eight
+            // v_cndmask_b32 (second-port class; tools/ubench_issue.hip) from seven registers held through the loop
+            typedef float f4 __attribute__((ext_vector_type(4)));
+            f4 H = {fmaf(t, d.x, o.x), fmaf(t, d.y, o.y), fmaf(t, d.z, o.z), __int_as_float(kp)};   // march (src/Object.hs:151-153)
+            f4 T = {thr.x * m0.x, thr.y * m0.y, thr.z * m0.z, m0.w};                                // pixel * color (src/Lib.hs:79)
             unsigned long long saved;
-            asm("s_and_saveexec_b64 %[sv], %[m]\n\t"
-                "v_mov_b32 %[i], %[ci]\n\t"
-                "v_mov_b32 %[hx], %[px]\n\t"
-                "v_mov_b32 %[hy], %[py]\n\t"
-                "v_mov_b32 %[hz], %[pz]\n\t"
-                "v_mov_b32 %[tx], %[cx]\n\t"
-                "v_mov_b32 %[ty], %[cy]\n\t"
-                "v_mov_b32 %[tz], %[cz]\n\t"
-                "v_mov_b32 %[c], %[cr]\n\t"
-                "s_mov_b64 exec, %[sv]"
-                : [i] "+v"(idxp), [hx] "+v"(hp.x), [hy] "+v"(hp.y), [hz] "+v"(hp.z), [tx] "+v"(thr.x), [ty] "+v"(thr.y),
-                  [tz] "+v"(thr.z), [c] "+v"(c1), [sv] "=&s"(saved)
-                : [m] "s"(tm), [ci] "v"(cidxp), [px] "v"(cP0.x), [py] "v"(cP0.y), [pz] "v"(cP0.z), [cx] "v"(ccol.x),
-                  [cy] "v"(ccol.y), [cz] "v"(ccol.z), [cr] "v"(c1r));
-            if constexpr (SPEC) {                          // the specular bounce also reads the tag and the incoming direction
-                asm("s_and_saveexec_b64 %[sv], %[m]\n\t"
-                    "v_mov_b32 %[e], %[ce]\n\t"
-                    "v_mov_b32 %[dx], %[qx]\n\t"
-                    "v_mov_b32 %[dy], %[qy]\n\t"
-                    "v_mov_b32 %[dz], %[qz]\n\t"
-                    "s_mov_b64 exec, %[sv]"
-                    : [e] "+v"(e), [dx] "+v"(din.x), [dy] "+v"(din.y), [dz] "+v"(din.z), [sv] "=&s"(saved)
-                    : [m] "s"(tm), [ce] "v"(ce), [qx] "v"(cd0.x), [qy] "v"(cd0.y), [qz] "v"(cd0.z));
+            if constexpr (SPEC) {                          // the specular bounce also reads the incoming direction
+                f4 D = {d.x, d.y, d.z, 0.f};
+                asm volatile("s_and_saveexec_b64 %[sv], %[m]\n\t"
+                             "ds_read_b128 %[H], %[ad]\n\t"
+                             "ds_read_b128 %[T], %[ad] offset:16\n\t"
+                             "ds_read_b128 %[D], %[ad] offset:32\n\t"
+                             "v_mov_b32 %[c], %[cr]\n\t"
+                             "s_waitcnt lgkmcnt(0)\n\t"
+                             "s_mov_b64 exec, %[sv]"
+                             : [H] "+v"(H), [T] "+v"(T), [D] "+v"(D), [c] "+v"(c1), [sv] "=&s"(saved)
+                             : [m] "s"(tm), [ad] "v"(raddr), [cr] "v"(c1r) : "memory");
+                din = mk3(D.x, D.y, D.z);
+            } else {
+                asm volatile("s_and_saveexec_b64 %[sv], %[m]\n\t"
+                             "ds_read_b128 %[H], %[ad]\n\t"
+                             "ds_read_b128 %[T], %[ad] offset:16\n\t"
+                             "v_mov_b32 %[c], %[cr]\n\t"
+                             "s_waitcnt lgkmcnt(0)\n\t"
+                             "s_mov_b64 exec, %[sv]"
+                             : [H] "+v"(H), [T] "+v"(T), [c] "+v"(c1), [sv] "=&s"(saved)
+                             : [m] "s"(tm), [ad] "v"(raddr), [cr] "v"(c1r) : "memory");
+                din = d;
             }
+            hp = mk3(H.x, H.y, H.z); idxp = __float_as_int(H.w);
+            thr = mk3(T.x, T.y, T.z); e = T.w;
         } else {
             c1 = terminal ? c1r : c1;
             idxp = terminal ? cidxp : kp;
@@ -1269,9 +1273,14 @@ __global__ __launch_bounds__(STATIC_BLOCK) void trace_static_kernel(TraceArgs a,
                             atomicAdd(&s_acc[cur * 3 + 2], acc.z);
                             acc = mk3(0.f, 0.f, 0.f);
                             cur = v;
-                            const float4 p0 = s_pix[v * 3 + 0], p1 = s_pix[v * 3 + 1], p2 = s_pix[v * 3 + 2];
-                            cP0 = mk3(p0.x, p0.y, p0.z); cd0 = mk3(p0.w, p1.x, p1.y); ccol = mk3(p1.z, p1.w, p2.x);
-                            cidxp = __float_as_int(p2.y); ce = p2.z;
+                            raddr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)&s_pix[v * 3];
+                            const float4 p0 = s_pix[v * 3 + 0];
+                            cidxp = __float_as_int(p0.w);
+                            if constexpr (!MASKS) {        // the select form keeps the restart constants in registers
+                                const float4 p1 = s_pix[v * 3 + 1], p2 = s_pix[v * 3 + 2];
+                                cP0 = mk3(p0.x, p0.y, p0.z); ccol = mk3(p1.x, p1.y, p1.z); ce = p1.w;
+                                cd0 = mk3(p2.x, p2.y, p2.z);
+                            }
                             pre = (uint64_t)0xD256D193u * (uint64_t)(uint32_t)(pixel0 + v);
                         }
                         needy = false;
