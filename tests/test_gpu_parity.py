@@ -304,9 +304,9 @@ def test_work_sharing_renders_the_same_paths(pa, H, W, spp, bounces):
     assert b.sum() > 0
 
 
-@pytest.mark.parametrize("H,W,spp", [(40, 56, 256), (33, 32, 700), (64, 64, 513)])
+@pytest.mark.parametrize("H,W,spp", [(40, 56, 512), (33, 32, 700), (64, 64, 513)])
 def test_sample_slices_of_a_large_launch(pa, H, W, spp):
-    """A launch of >= 256 samples runs as two sample slices (the last 1/16 of the
+    """A launch of >= 512 samples runs as two sample slices (the last 1/16 of the
     samples in workgroups of their own, summed into the canvas by a second kernel):
     same paths, same count of searches, sums equal up to fp32 summation order --
     against the strict kernel (never sliced), against two launches that are too
@@ -317,7 +317,7 @@ def test_sample_slices_of_a_large_launch(pa, H, W, spp):
         sliced.trace(spp)
         strict.trace(spp)
         k = 0
-        while k < spp:                                   # launches of < 256 samples: whole
+        while k < spp:                                   # launches of < 512 samples: whole
             n = min(200, spp - k)
             small.trace(n); k += n
         cont.trace(5)
@@ -398,9 +398,9 @@ def test_sample_split_union(pa):
 # ------------------------------------------------------------- output --------
 def test_sample_split_union_with_sliced_launches(pa):
     """The same union when every shard's launch is large enough to run as two
-    sample slices (>= 256 samples) and strides its global sample indices: three
-    shards of 300 against one context's 900 samples."""
-    H, W, G, per = 32, 48, 3, 300
+    sample slices (>= 512 samples) and strides its global sample indices: three
+    shards of 520 against one context's 1560 samples."""
+    H, W, G, per = 32, 48, 3, 520
     P = pa.Params(H, W, 500.0, G * per, 8)
     with pa.Renderer(P, seed=11) as full:
         full.trace(G * per)
