@@ -28,8 +28,7 @@ struct pt_ctx {
     double *d_prim = nullptr;
     float4 *d_pix = nullptr;           // primary hits kept across launches (TraceArgs::pix); valid until the next scene upload
     bool pix_valid = false;
-    float *d_partial = nullptr;        // the second sample slice's plane and the tiles' tickets (pt_internal.hpp),
-    uint32_t *d_ticket = nullptr;      //   allocated at the first large pt_trace
+    float *d_partial = nullptr;        // sample-slice planes of a launch (pt_internal.hpp), allocated at the first large pt_trace
     float4 *d_rect = nullptr;          // sides of Rectangle forms, 2 float4 per object; null without one
     float4 *d_bvh_nodes = nullptr;               // spatial index over the finite forms (pt_bvh.hpp), or null
     int32_t *d_bvh_prims = nullptr;
@@ -277,7 +276,6 @@ void pt_destroy(pt_ctx *c)
     if (c->d_prim) (void)hipFree(c->d_prim);
     if (c->d_rect) (void)hipFree(c->d_rect);
     if (c->d_partial) (void)hipFree(c->d_partial);
-    if (c->d_ticket) (void)hipFree(c->d_ticket);
     if (c->d_pix) (void)hipFree(c->d_pix);
     if (c->d_bvh_nodes) (void)hipFree(c->d_bvh_nodes);
     if (c->d_bvh_prims) (void)hipFree(c->d_bvh_prims);
@@ -419,17 +417,10 @@ int pt_trace(pt_ctx *c, int32_t iters)
     const bool reuse = !(c->p.flags & PT_FLAG_NO_PRIMARY_REUSE);
     // planes for the sample slices of trace_static_kernel (small scenes, default flags, large launches)
     if (!c->d_partial && iters >= SLICE_MIN_SAMPLES && c->n_obj <= MAX_STATIC_OBJECTS && reuse && !(c->p.flags & PT_FLAG_NO_STEAL))
-    {
-        const size_t tiles = (npix(c) + 63) / 64;
-        if (hipMalloc((void **)&c->d_partial, npix(c) * 3 * sizeof(float)) != hipSuccess ||
-            hipMalloc((void **)&c->d_ticket, tiles * sizeof(uint32_t)) != hipSuccess ||
-            hipMemsetAsync(c->d_ticket, 0, tiles * sizeof(uint32_t), c->stream) != hipSuccess) {
-            (void)hipGetLastError();                 // no memory for the plane: launches stay unsliced
-            if (c->d_partial) (void)hipFree(c->d_partial);
-            if (c->d_ticket) (void)hipFree(c->d_ticket);
-            c->d_partial = nullptr; c->d_ticket = nullptr;
+        if (hipMalloc((void **)&c->d_partial, (size_t)(MAX_SLICES - 1) * npix(c) * 3 * sizeof(float)) != hipSuccess) {
+            (void)hipGetLastError();                 // no memory for the planes: launches stay unsliced
+            c->d_partial = nullptr;
         }
-    }
     const bool static_path = c->n_obj <= MAX_STATIC_OBJECTS && reuse && !(c->p.flags & PT_FLAG_NO_STEAL);
     if (static_path && !c->d_pix)
         if (hipMalloc((void **)&c->d_pix, npix(c) * 2 * sizeof(float4)) != hipSuccess) {
@@ -449,7 +440,7 @@ int pt_trace(pt_ctx *c, int32_t iters)
         a.sample_begin = (uint32_t)(c->p.sample_offset + c->samples_done * c->p.sample_stride);
         a.sample_stride = (uint32_t)c->p.sample_stride;
         a.n_samples = n;
-        a.partial = c->d_partial; a.slice_ticket = c->d_ticket;
+        a.partial = c->d_partial;
         a.pix = static_path ? c->d_pix : nullptr; a.pix_valid = a.pix && c->pix_valid ? 1 : 0;
         PT_HIP(c, launch_trace(a, c->h_geom.data(), reuse, c->has_specular,
                                (c->p.flags & PT_FLAG_LDS_TILES) != 0,

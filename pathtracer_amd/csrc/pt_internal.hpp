@@ -46,15 +46,14 @@ struct TraceArgs {
     const float4  *bvh_nodes;          // 1 float4 per node: six binary16 box bounds + code (pt_bvh.hpp)
     const int32_t *bvh_prims;          // [unbounded objects..., finite objects in leaf order...]
     const float4  *bvh_geom;           // geometry records in bvh_prims order (3 float4 each, object index in [2].w), padded
+    // Sample slices of one launch (trace_static_kernel): slice y = blockIdx.y traces samples
+    // [slice_j0[y], slice_j0[y] + slice_n[y]) of the launch's n_samples; slice 0 continues the canvas, slice
+    // y > 0 writes plane y - 1 of `partial`, and slice_sum_kernel adds the planes to the canvas in order.
     // The primary hits (fp64 pass, per pixel: point, direction, record offset) of this camera and scene, kept
     // from the first launch for all later ones (trace_static_kernel): 2 float4 per pixel, or null
     float4  *pix;
     int      pix_valid;                // 1: read them, 0: compute (and store if pix != null)
-    // Sample slices of one launch (trace_static_kernel): slice y = blockIdx.y traces samples
-    // [slice_j0[y], slice_j0[y] + slice_n[y]) of the launch's n_samples; slice 0 continues the canvas, slice 1
-    // writes the plane `partial`, and the last of a tile's two workgroups to finish adds the two (slice 0's first).
-    float   *partial;                  // H*W*3 floats, or null: no slicing
-    uint32_t *slice_ticket;            // one counter per 64-pixel tile, zero at allocation, +2 per sliced launch
+    float   *partial;                  // (MAX_SLICES - 1) * H*W*3 floats, or null: no slicing
     int      n_slices;
     int      slice_j0[MAX_SLICES], slice_n[MAX_SLICES];
     int      n_nodes;

@@ -5,7 +5,7 @@
 //                         scenes of <= 8 objects (object list in the kernel
 //                         arguments): THE hot kernel, the one bench.py times.
 //                         Large launches run as two sample slices of one grid;
-//                         a tile's last workgroup adds the two sums.
+//                         slice_sum_kernel adds the second slice's plane.
 //   trace_bvh_kernel    : larger scenes searched through the spatial index:
 //                         resumable per-lane searches, the wave alternates walk
 //                         and shade steps.
@@ -1310,27 +1310,20 @@ __global__ __launch_bounds__(STATIC_BLOCK) void trace_static_kernel(TraceArgs a,
         canvas[3 * (size_t)pc + 2] = s_acc[tid * 3 + 2];
     }
     if (tid == 0 && s_segs) atomicAdd(seg_lane(a.segments), s_segs);
-    if (a.n_slices == 2) {
-        // Two sample slices: whichever of a tile's two workgroups finishes LAST adds the two sums, slice 0's
-        // first, and stores the canvas -- the same value whoever it is, so the result does not depend on the
-        // order of arrival (and no separate summing kernel has to find free CUs behind the next frame's trace).
-        // Every sliced launch takes two tickets per tile, so a ticket's parity tells who is last.
-        __shared__ uint32_t s_ticket;
-        __threadfence();                                   // my sums are visible device-wide before my ticket is
-        __syncthreads();
-        if (tid == 0) s_ticket = atomicAdd(&a.slice_ticket[blockIdx.x], 1u);
-        __syncthreads();
-        if ((s_ticket & 1u) && in_canvas) {
-            __threadfence();                               // acquire: the other workgroup's stores, not a stale line
-            const float *other = slice == 0 ? a.partial : a.canvas;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const float mine = s_acc[tid * 3 + c];
-                const float theirs = __hip_atomic_load(&other[3 * (size_t)pc + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                a.canvas[3 * (size_t)pc + c] = slice == 0 ? mine + theirs : theirs + mine;
-            }
-        }
+}
+
+// canvas += plane 0 + plane 1 + ... (in this order): the sample slices of one launch
+__global__ __launch_bounds__(256) void slice_sum_kernel(float4 *__restrict__ canvas, const float4 *__restrict__ partial,
+                                                        size_t n4, int planes)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    float4 s = canvas[i];
+    for (int p = 0; p < planes; ++p) {
+        const float4 q = partial[(size_t)p * n4 + i];
+        s.x += q.x; s.y += q.y; s.z += q.z; s.w += q.w;
     }
+    canvas[i] = s;
 }
 
 template <int NS>
@@ -1364,14 +1357,22 @@ static hipError_t launch_trace_ns(TraceArgs a, const float4 *geom_host, bool reu
             // 2 % slower than one slice when consecutive frames overlap, which two slices are not).
             const int n = a.n_samples;
             a.n_slices = 1; a.slice_j0[0] = 0; a.slice_n[0] = n;
-            if (a.partial && a.slice_ticket && n >= SLICE_MIN_SAMPLES) {
+            if (a.partial && npix % 4 == 0 && n >= SLICE_MIN_SAMPLES) {
                 a.n_slices = 2;
                 a.slice_n[1] = n / 16; a.slice_n[0] = n - a.slice_n[1]; a.slice_j0[1] = a.slice_n[0];
             }
             const dim3 sgrid((npix + STATIC_BLOCK - 1) / STATIC_BLOCK, a.n_slices), sblock(STATIC_BLOCK);
             if (spec) hipLaunchKernelGGL((trace_static_kernel<NS, true>), sgrid, sblock, 0, s, a, sg);
             else      hipLaunchKernelGGL((trace_static_kernel<NS, false>), sgrid, sblock, 0, s, a, sg);
-            return hipGetLastError();
+            hipError_t e = hipGetLastError();
+            if (e == hipSuccess && a.n_slices > 1) {
+                const size_t n4 = (size_t)npix * 3 / 4;
+                hipLaunchKernelGGL(slice_sum_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s,
+                                   reinterpret_cast<float4 *>(a.canvas), reinterpret_cast<const float4 *>(a.partial), n4,
+                                   a.n_slices - 1);
+                e = hipGetLastError();
+            }
+            return e;
         }
     }
     if constexpr (NS == 0 || NS == -2) {
