@@ -1186,19 +1186,24 @@ __global__ __launch_bounds__(STATIC_BLOCK) void trace_static_kernel(TraceArgs a,
                              : [H] "+v"(H), [T] "+v"(T), [D] "+v"(D), [c] "+v"(c1), [sv] "=&s"(saved)
                              : [m] "s"(tm), [ad] "v"(raddr), [cr] "v"(c1r) : "memory");
                 din = mk3(D.x, D.y, D.z);
+                thr = mk3(T.x, T.y, T.z); e = T.w;
             } else {
+                // (the diffuse bounce does not read the tag: a 96-bit read straight into the throughput's registers;
+                // with the tag as a fourth element hipcc formed the tuple elsewhere and copied it back, 3 v_mov)
+                typedef float f3v __attribute__((ext_vector_type(3)));
+                f3v T3 = {thr.x * m0.x, thr.y * m0.y, thr.z * m0.z};
                 asm volatile("s_and_saveexec_b64 %[sv], %[m]\n\t"
                              "ds_read_b128 %[H], %[ad]\n\t"
-                             "ds_read_b128 %[T], %[ad] offset:16\n\t"
+                             "ds_read_b96 %[T], %[ad] offset:16\n\t"
                              "v_mov_b32 %[c], %[cr]\n\t"
                              "s_waitcnt lgkmcnt(0)\n\t"
                              "s_mov_b64 exec, %[sv]"
-                             : [H] "+v"(H), [T] "+v"(T), [c] "+v"(c1), [sv] "=&s"(saved)
+                             : [H] "+v"(H), [T] "+v"(T3), [c] "+v"(c1), [sv] "=&s"(saved)
                              : [m] "s"(tm), [ad] "v"(raddr), [cr] "v"(c1r) : "memory");
                 din = d;
+                thr = mk3(T3.x, T3.y, T3.z); e = m0.w;
             }
             hp = mk3(H.x, H.y, H.z); idxp = __float_as_int(H.w);
-            thr = mk3(T.x, T.y, T.z); e = T.w;
         } else {
             c1 = terminal ? c1r : c1;
             idxp = terminal ? cidxp : kp;
