@@ -44,3 +44,19 @@ def test_default_kernel_equals_strict_kernel(pa, H, W, chunks, bounces):
     assert np.all(np.isfinite(a))
     assert np.allclose(a, b, rtol=1e-5, atol=1e-5)
     assert b.sum() > 0
+
+
+@pytest.mark.parametrize("H,W,spp,bounces,n", [(7, 9, 40, 8, 50), (1, 1, 300, 16, 200), (65, 3, 9, 64, 1025),
+                                               (64, 64, 2, 2, 300), (33, 31, 17, 5, 2500)])
+def test_indexed_kernel_equals_strict_kernel(pa, H, W, spp, bounces, n):
+    """trace_bvh_kernel (resumable searches, walk and shade steps, the wave's sample
+    pool) against the strict kernel on the same indexed scene."""
+    objs = pa.random_disk_scene(n, 40 + n)
+    P = pa.Params(H, W, 60.0, spp, bounces)
+    with pa.Renderer(P, objs, seed=2) as fast, pa.Renderer(P, objs, seed=2, flags=pa.PT_FLAG_NO_STEAL) as strict:
+        fast.trace(spp)
+        strict.trace(spp)
+        a, b = fast.read_sum_f32(), strict.read_sum_f32()
+        assert fast.segments == strict.segments
+    assert np.all(np.isfinite(a))
+    assert np.allclose(a, b, rtol=1e-5, atol=1e-5)
