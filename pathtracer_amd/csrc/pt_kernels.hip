@@ -655,9 +655,9 @@ __global__ __launch_bounds__(NS == -2 ? 64 : TRACE_BLOCK) void trace_steal_kerne
 // waiting for the slowest: 22 % of the lanes were active.  Here a lane's search
 // is a resumable state (node, stack depth, best hit so far) and the wave
 // alternates between two steps:
-//   walk  : every lane that is searching visits up to BVH_ROUND_VISITS nodes and
+//   walk  : every lane that is searching visits up to PT_BVH_ROUND_VISITS nodes and
 //           at most one leaf;
-//   shade : the lanes whose search has finished (as soon as BVH_SHADE_LANES of
+//   shade : the lanes whose search has finished (as soon as PT_BVH_SHADE_LANES of
 //           them wait, or nobody is searching) take the radiance, bounce or
 //           restart -- drawing the next sample from the wave's pool exactly as
 //           trace_steal_kernel's sharing phase does -- and start their next
@@ -668,7 +668,7 @@ __global__ __launch_bounds__(NS == -2 ? 64 : TRACE_BLOCK) void trace_steal_kerne
 // ---------------------------------------------------------------------------
 constexpr int BVH_BLOCK = 64;
 #ifndef PT_BVH_ROUND_VISITS
-#define PT_BVH_ROUND_VISITS 12
+#define PT_BVH_ROUND_VISITS 8
 #endif
 #ifndef PT_BVH_SHADE_LANES
 #define PT_BVH_SHADE_LANES 12
