@@ -237,7 +237,8 @@ def main():
                          "unit": "TFLOP/s", "frac": round(achieved / FP32_VALU_PEAK_TFLOPS, 4),
                          "traffic": traffic,
                          "kernel": "trace_kernel" if (args.no_steal or args.no_primary_reuse) else
-                                   ("trace_static_kernel" if len(scene) <= 8 else "trace_steal_kernel"),
+                                   ("trace_static_kernel" if len(scene) <= 8 else
+                                    "trace_bvh_kernel" if indexed else "trace_steal_kernel"),
                          "kernel_ms": round(kern_ms, 4),
                          "flops_per_segment": F, "segments_per_launch": int(segs_launch_rank0),
                          "note": "fp32 VALU-bound path (no MFMA, ~0 HBM bytes per segment); peak = fp32 vector "
