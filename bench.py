@@ -87,6 +87,8 @@ def main():
                     help="default | disks1000 | spheres1000 | disks10000 | spheres10000: the synthetic scenes of "
                          "BASELINE.json configs[3]/[4] (SURVEY.md 8d generator); pass their --height/--width/--spp/--bounces")
     ap.add_argument("--no-bvh", action="store_true", help="PT_FLAG_NO_BVH: linear scan over all objects")
+    ap.add_argument("--no-specialise", action="store_true",
+                    help="keep the general trace kernel: no pt_scene_specialise (kernel compiled for the scene) at set-up")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="trace, all-reduce and output strictly in line instead of overlapped with the next frame")
     args = ap.parse_args()
@@ -138,6 +140,13 @@ def main():
     pipelined = not args.no_pipeline         # the same frame loop for every N; N = 1 simply has no all-reduce
     rs = [pa.Renderer(P, scene, seed=0, device=local_rank, sample_offset=s_off, sample_stride=s_stride,
                       flags=flags) for _ in range(2 if pipelined else 1)]
+    # set-up, like the scene upload: the trace kernel compiled for this scene (pt_scene_specialise; by-value
+    # scenes on the default flags only -- elsewhere, or without hiprtc on the machine, the general kernel stays)
+    specialised = False
+    if not args.no_specialise and len(scene) <= 8 and not (args.no_steal or args.no_primary_reuse):
+        specialised = all([q.specialise() for q in rs])
+        if not specialised:
+            print("bench.py: pt_scene_specialise unavailable: " + rs[0].last_error(), file=sys.stderr)
     for q in rs:
         q.set_stream(stream.cuda_stream)      # kernels, all-reduce and events share this stream
     r = rs[0]
@@ -230,6 +239,9 @@ def main():
                        "segments_per_step": int(total_segs_step),
                        "paths_per_step": args.height * args.width * args.spp,
                        "primary_reuse": not args.no_primary_reuse,
+                       "scene_kernel": "compiled for this scene at set-up (pt_scene_specialise)" if specialised
+                                       else "general",
+
                        "parallelism": f"sample-split x{world}",
                        "frame_pipeline": "double-buffered: all-reduce + output of frame k overlap the trace of "
                                          "frame k+1" if pipe is not None else "none"},

@@ -37,7 +37,8 @@ typedef enum {
     PT_ERR_NO_DEVICE  = -2,   /* no HIP device / device index out of range      */
     PT_ERR_HIP        = -3,   /* a HIP runtime call failed; see pt_last_error   */
     PT_ERR_NO_SCENE   = -4,   /* pt_trace / pt_primary_hits before pt_scene_upload */
-    PT_ERR_LIMIT      = -5    /* a documented limit exceeded (objects, samples, bounces) */
+    PT_ERR_LIMIT      = -5,   /* a documented limit exceeded (objects, samples, bounces) */
+    PT_ERR_UNSUPPORTED = -6   /* an optional step does not apply here or cannot run; nothing changed (pt_scene_specialise) */
 } pt_status;
 
 /* Form constructors (src/Object.hs:51-56).  PT_SPHERE is an EXTENSION: the
@@ -213,6 +214,24 @@ int pt_dev_distance(pt_ctx *ctx, int32_t n, const pt_object *obj, const float *o
 /* Philox2x32-10 on the device for ctr=(c0[k], c1[k]), key: out[2k], out[2k+1]. */
 int pt_dev_philox(pt_ctx *ctx, int32_t n, const uint32_t *c0, const uint32_t *c1,
                   uint32_t key, uint32_t *out);
+
+/* Optional: compile the trace kernel for the uploaded scene.  No counterpart in
+ * the reference, where `objects` is a compile-time constant of the program
+ * anyway (src/Object.hs:147-148) -- this gives the device code the same
+ * knowledge.  The general kernel takes the object list as arguments and
+ * evaluates `(p - o).n / (v . n^)` (src/Object.hs:176-177) in full for every
+ * object; this call compiles the same kernel source at run time (hiprtc) with
+ * the scene's geometry as constants, so that terms with a zero coefficient
+ * (walls along the coordinate axes, as all four objects of the default scene
+ * are) are not computed.  The arithmetic that remains is the general kernel's
+ * rounding for rounding: images agree bit for bit, except that a ray direction
+ * with an exactly zero component may see -0 where the general form sees +0.
+ * Costs a compilation (seconds; cached per process, scene and device), so it is
+ * meant for a scene that will be traced for a while.  Applies to scenes of
+ * <= 8 objects on the default flags; the kernel is dropped by the next
+ * pt_scene_upload.  On PT_ERR_UNSUPPORTED (no libhiprtc on the machine, a scene
+ * or flags it does not cover) the context keeps using the general kernel. */
+int pt_scene_specialise(pt_ctx *ctx);
 
 /* Last kernel's launch duration in milliseconds, measured with HIP events on
  * the context's stream around the most recent pt_trace (all its launches).

@@ -12,6 +12,7 @@ LIB_PATH = os.environ.get("PT_LIBPT_PATH") or os.path.join(_HERE, "libpt.so")   
 
 PT_OK = 0
 PT_ERR_INVALID, PT_ERR_NO_DEVICE, PT_ERR_HIP, PT_ERR_NO_SCENE, PT_ERR_LIMIT = -1, -2, -3, -4, -5
+PT_ERR_UNSUPPORTED = -6
 PT_INFINITE_PLANE, PT_DISK, PT_SPHERE, PT_RECTANGLE = 0, 1, 2, 3
 PT_RGB8_REFERENCE, PT_RGB8_MEAN_CLAMP, PT_RGB8_MEAN_GAMMA = 0, 1, 2
 PT_FLAG_NO_PRIMARY_REUSE = 1
@@ -81,6 +82,7 @@ SIGNATURES = {
     "pt_dev_specular": (C.c_int, [_P, C.c_int32, _P, _P, _P, C.c_float, _P]),
     "pt_dev_distance": (C.c_int, [_P, C.c_int32, C.POINTER(pt_object), _P, _P, _P]),
     "pt_dev_philox": (C.c_int, [_P, C.c_int32, _P, _P, C.c_uint32, _P]),
+    "pt_scene_specialise": (C.c_int, [_P]),
     "pt_set_timing": (C.c_int, [_P, C.c_int32]),
     "pt_last_trace_ms": (C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_int32)]),
     "pt_last_error": (C.c_char_p, [_P]),

@@ -38,6 +38,7 @@ struct pt_ctx {
     int n_obj = 0;
     bool has_specular = false;
     std::vector<float4> h_geom;   // host copy: small scenes ride in the kernel arguments
+    hipFunction_t scene_kernel = nullptr;   // trace_static_kernel compiled for this scene (pt_scene_specialise), or null
     int64_t samples_done = 0;
     bool timing = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -209,6 +210,7 @@ const char *pt_status_string(int s)
     case PT_ERR_HIP: return "HIP runtime error";
     case PT_ERR_NO_SCENE: return "no scene uploaded";
     case PT_ERR_LIMIT: return "limit exceeded";
+    case PT_ERR_UNSUPPORTED: return "optional step not available";
     default: return "unknown status";
     }
 }
@@ -341,6 +343,7 @@ int pt_scene_upload(pt_ctx *c, const pt_object *objs, int32_t n)
         PT_HIP(c, hipMemcpy(c->d_rect, rect.data(), rect.size() * sizeof(float4), hipMemcpyHostToDevice));
     }
     c->h_geom = geom;
+    c->scene_kernel = nullptr;                   // belongs to the previous scene
     c->n_obj = n;
     c->has_specular = spec;
 
@@ -444,7 +447,8 @@ int pt_trace(pt_ctx *c, int32_t iters)
         a.pix = static_path ? c->d_pix : nullptr; a.pix_valid = a.pix && c->pix_valid ? 1 : 0;
         PT_HIP(c, launch_trace(a, c->h_geom.data(), reuse, c->has_specular,
                                (c->p.flags & PT_FLAG_LDS_TILES) != 0,
-                               (c->p.flags & PT_FLAG_NO_STEAL) == 0, c->stream));
+                               (c->p.flags & PT_FLAG_NO_STEAL) == 0, c->stream,
+                               static_path ? c->scene_kernel : nullptr));
         if (a.pix) c->pix_valid = true;              // later launches on this stream read what this one stored
         c->canvas_stale = false;
         c->samples_done += n;
@@ -456,6 +460,21 @@ int pt_trace(pt_ctx *c, int32_t iters)
         c->last_launches = launches;
         c->have_timing = true;
     }
+    return PT_OK;
+}
+
+int pt_scene_specialise(pt_ctx *c)
+{
+    if (int s = check_ctx(c)) return s;
+    if (c->n_obj < 1) return fail(c, PT_ERR_NO_SCENE, "pt_scene_specialise: no scene uploaded");
+    if (c->n_obj > MAX_STATIC_OBJECTS)
+        return fail(c, PT_ERR_UNSUPPORTED, "pt_scene_specialise: only scenes of <= 8 objects have a kernel to specialise");
+    if (c->p.flags & (PT_FLAG_NO_STEAL | PT_FLAG_NO_PRIMARY_REUSE))
+        return fail(c, PT_ERR_UNSUPPORTED, "pt_scene_specialise: the strict kernels are not specialised");
+    std::string why;
+    hipFunction_t fn = jit_static_kernel(c->p.device, c->n_obj, c->has_specular, c->h_geom.data(), why);
+    if (!fn) return fail(c, PT_ERR_UNSUPPORTED, "pt_scene_specialise: " + why + " (the general kernel stays in use)");
+    c->scene_kernel = fn;
     return PT_OK;
 }
 

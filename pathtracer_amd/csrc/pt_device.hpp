@@ -16,8 +16,16 @@
 // File:line citations are relative to the reference repository root.
 #pragma once
 
+#ifndef __HIPCC_RTC__          // hiprtc brings its own runtime header and the fixed-width integer types
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#else
+typedef signed char int8_t;       typedef unsigned char uint8_t;
+typedef short int16_t;            typedef unsigned short uint16_t;
+typedef int int32_t;              typedef unsigned int uint32_t;
+typedef long int64_t;             typedef unsigned long uint64_t;
+typedef unsigned long uintptr_t;
+#endif
 
 namespace pt {
 

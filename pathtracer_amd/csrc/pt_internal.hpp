@@ -2,8 +2,10 @@
 // C ABI implementation.  Not part of the public interface (include/pt.h is).
 #pragma once
 
+#ifndef __HIPCC_RTC__          // hiprtc brings its own runtime header and the fixed-width integer types
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#endif
 
 #include "pt_device.hpp"
 
@@ -61,9 +63,13 @@ struct TraceArgs {
     int      n_unbounded;
 };
 
+#ifndef __HIPCC_RTC__
 // Launchers (pt_kernels.hip).  All return the hipError_t of the launch.
+// `scene_kernel`: trace_static_kernel compiled for this scene (jit_static_kernel), launched in place of the
+// general one where that would run; null: none.
 hipError_t launch_trace(const TraceArgs &a, const float4 *geom_host, bool reuse_primary,
-                        bool has_specular, bool lds_tiles, bool steal, hipStream_t s);
+                        bool has_specular, bool lds_tiles, bool steal, hipStream_t s,
+                        hipFunction_t scene_kernel = nullptr);
 hipError_t launch_primary(const TraceArgs &a, int32_t *idx, double *t, double *normal, hipStream_t s);
 hipError_t launch_rgb8(const float *canvas, uint8_t *rgb, int H, int W, int mode,
                        double inv_samples, hipStream_t s);
@@ -74,5 +80,15 @@ hipError_t launch_dev_distance(int n, const float4 *geom1_rect, const float *o, 
                                float *t, hipStream_t s);
 hipError_t launch_dev_philox(int n, const uint32_t *c0, const uint32_t *c1, uint32_t key,
                              uint32_t *out, hipStream_t s);
+#endif
+
+#ifndef __HIPCC_RTC__
+} // namespace pt
+#include <string>
+namespace pt {
+// pt_jit.hip: trace_static_kernel<NS, spec> compiled by hiprtc with this geometry (n_obj * 3 float4, as uploaded)
+// as constants, loaded on `device`; cached per process.  Null and a reason in `err` on failure.
+hipFunction_t jit_static_kernel(int device, int n_obj, bool spec, const float4 *geom_host, std::string &err);
+#endif
 
 } // namespace pt

@@ -35,19 +35,13 @@
 //   in SGPRs / wave-uniform VGPRs; materials are per-lane gathers from an LDS
 //   copy staged once per workgroup.
 #include "pt_internal.hpp"
+#include "pt_static_kernel.hpp"
 
 #include <cstdlib>
 #include <type_traits>
 
 namespace pt {
 
-// The segment counter of one pt_reset epoch is SEG_LANES counters in separate
-// 128-byte lines, picked by workgroup: atomics on ONE address retire at ~80 M/s
-// in L2 (8,100 workgroups = 0.1 ms, measured on an otherwise empty launch).
-__device__ __forceinline__ unsigned long long *seg_lane(unsigned long long *base)
-{
-    return base + (blockIdx.x & (SEG_LANES - 1)) * SEG_LANE_STRIDE;
-}
 
 // ---------------------------------------------------------------------------
 // closest-hit search (closestObjectTo, src/Lib.hs:81-98)
@@ -133,14 +127,6 @@ __device__ __forceinline__ void key_result(int &best, uint32_t best_key, float &
     best_t = __uint_as_float(best_key + 1u);
 }
 
-// the per-pixel fp64 primary segment, through the spatial index when the scene has one
-__device__ __forceinline__ PrimaryHit primary_hit(const TraceArgs &a, int pi, int pj, int *stack = nullptr, int stride = 0)
-{
-    if (a.n_nodes > 0 && stack)
-        return primary_hit_f64_bvh(a.prim, a.bvh_nodes, a.bvh_prims, a.n_unbounded, a.height, a.width,
-                                   a.camera_depth, pi, pj, stack, stride);
-    return primary_hit_f64(a.prim, a.n_obj, a.height, a.width, a.camera_depth, pi, pj);
-}
 
 // LDS tile of geometry records for the tiled kernel (NS == -1), dynamic size.
 extern __shared__ float4 s_tile[];
@@ -902,420 +888,6 @@ __global__ __launch_bounds__(BVH_BLOCK) void trace_bvh_kernel(TraceArgs a)
     if ((tid & 63) == 0 && wsegs) atomicAdd(seg_lane(a.segments), wsegs);
 }
 
-// ---------------------------------------------------------------------------
-// trace kernel for small scenes (object list in the kernel arguments), the
-// default for <= 8 objects.  Same two phases and the same work sharing as
-// trace_steal_kernel; what differs is the instruction diet, shaped by the issue
-// rules measured with tools/ubench_issue.hip on gfx950:
-//   * a VALU instruction with an SGPR operand issues once per 4 cycles, an
-//     all-VGPR add/mul/fma/logic op once per 2, and compares, selects, min/max,
-//     converts, integer multiplies and three-operand integer ops once per 4 on a
-//     port of their own; the three limits overlap, so the loop is laid out to
-//     load them evenly: n_hat stays in SGPRs (den = v.n_hat), n_raw and A move to
-//     VGPRs, and the Philox round keys and multiplier are VGPRs too;
-//   * object identity is carried as the byte offset 16*(k+1) of the object's
-//     material record (0 = the "miss" record), so the closest-hit search selects
-//     LDS addresses directly from inline constants: no index arithmetic;
-//   * the material tag m0.w orders the cases (light e > 0, miss 0, diffuse -1,
-//     reflective -2): "path ends here" is one compare and the emitted radiance
-//     max(e, 0) one integer max, with no select on hit/miss;
-//   * sample index and bounce live in one counter (gs << 6 | bounce) that is
-//     also the Philox counter word and the loop's exit test;
-//   * (4-object list) identity and control decisions are lane masks kept on the
-//     scalar unit: _lastStruck is one mask per object, updated from the accept
-//     masks of the search with s_and/s_or/s_andn2; where such a mask exists,
-//     values are moved in under exec (v_mov_b32, plain issue class) instead of
-//     being selected (v_cndmask_b32, second-port class).
-// ---------------------------------------------------------------------------
-// MASKS: the _lastStruck exclusion arrives as one lane mask per object
-// (excl[k] = lanes whose last-struck object is k) and every accept decision is
-// returned as a lane mask (okm[k]); the caller derives the next masks from them
-// on the scalar unit, so the search spends no vector compare on identity.
-// best <- (OFF, key) in the lanes of `mask`: two plain-class moves under exec
-// instead of two second-port selects
-template <int OFF>
-__device__ __forceinline__ void take_under(unsigned long long mask, int &bestp, uint32_t &best_key, uint32_t key)
-{
-    unsigned long long saved;
-    asm("s_and_saveexec_b64 %[sv], %[m]\n\t"
-        "v_mov_b32 %[bp], %[off]\n\t"
-        "v_mov_b32 %[bk], %[key]\n\t"
-        "s_mov_b64 exec, %[sv]"
-        : [bp] "+v"(bestp), [bk] "+v"(best_key), [sv] "=&s"(saved)
-        : [m] "s"(mask), [off] "n"(OFF), [key] "v"(key));
-}
-
-template <int NS, bool SPH, bool MASKS>
-__device__ __forceinline__ void closest_static(const StaticGeom<NS> &sg, const float4 *__restrict__ rect, f3 o, f3 v, int lastp,
-                                               const unsigned long long *excl, unsigned long long *okm,
-                                               int &bestp, float &best_t)
-{
-    // The bits of t order the candidates as unsigned integers: finite positive t
-    // below bits(+Inf); t <= -0, NaN and +Inf at or above it.  t = +0 alone would
-    // pass (0 < t is strict, src/Object.hs:159), so the product is formed as
-    // fma(num, 1/den, -denorm_min): +0 becomes negative, every other value is
-    // unchanged by the rounding.  A strict '<' keeps the earlier object on ties.
-    uint32_t best_key = 0x7f800000u;
-    bestp = 0;
-#pragma unroll
-    for (int k = 0; k < NS; ++k) {
-        const float4 g0 = sg.g[k][0], g1 = sg.g[k][1], g2 = sg.g[k][2];
-        // A - o.n_raw with the dot folded into A (g0.xyz holds -n_raw here, see the kernel's set-up): the
-        // same three roundings as distance_from's fma(-o, n, .) chain
-        const float num = fmaf(o.z, g0.z, fmaf(o.y, g0.y, fmaf(o.x, g0.x, g0.w)));
-        const float den = fmaf(v.z, g1.z, fmaf(v.y, g1.y, v.x * g1.x));
-        float t = fmaf(num, __builtin_amdgcn_rcpf(den), -__builtin_bit_cast(float, 1u));
-        if constexpr (SPH) {
-            if (g1.w < 0.0f)                                       // wave-uniform: Sphere (extension)
-                t = fmaf(sphere_t(mk3(g2.x, g2.y, g2.z), -g1.w, o, v), 1.0f, -__builtin_bit_cast(float, 1u));
-        }
-        const uint32_t key = __float_as_uint(t);
-        // 0 < t < best, not _lastStruck (src/Lib.hs:86-90)
-        bool ok = false;
-        unsigned long long m = 0;
-        if constexpr (MASKS) m = __builtin_amdgcn_ballot_w64(key < best_key) & ~excl[k];
-        else ok = (key < best_key) & (16 * (k + 1) != lastp);
-        if (g1.w != __builtin_inff() && !(SPH && g1.w < 0.0f)) {   // wave-uniform: Disk (src/Object.hs:165-171)
-            const float dx = fmaf(t, v.x, o.x) - g2.x;
-            const float dy = fmaf(t, v.y, o.y) - g2.y;
-            const float dz = fmaf(t, v.z, o.z) - g2.z;
-            const bool in = inside_form<SPH>(rect, k, g1.w, dx, dy, dz);
-            if constexpr (MASKS) m &= __builtin_amdgcn_ballot_w64(in);
-            else ok = ok & in;
-        }
-        if constexpr (MASKS) {
-            okm[k] = m;
-            switch (k) {                                           // k is a constant after unrolling
-            case 0:                                                // selects from constants: they also initialise
-                ok = __builtin_amdgcn_inverse_ballot_w64(m);
-                bestp = ok ? 16 : 0; best_key = ok ? key : 0x7f800000u;
-                break;
-            case 1: take_under<32>(m, bestp, best_key, key); break;
-            case 2: take_under<48>(m, bestp, best_key, key); break;
-            default: take_under<64>(m, bestp, best_key, key); break;
-            }
-        } else {
-            bestp = ok ? 16 * (k + 1) : bestp;
-            best_key = ok ? key : best_key;
-        }
-    }
-    best_t = __uint_as_float(best_key);
-}
-
-// One wave per workgroup: the finest dispatch grain, no barriers that wait on
-// other waves (measured 2 % faster than 256 at 1024 spp, 1 % at 128 spp).
-constexpr int STATIC_BLOCK = 64;
-
-template <int NS, bool SPEC>
-__global__ __launch_bounds__(STATIC_BLOCK) void trace_static_kernel(TraceArgs a, StaticGeom<NS> sg)
-{
-    static_assert(NS > 0, "object list by value");
-    constexpr int BLOCK = STATIC_BLOCK;
-    constexpr int R = NS + 1;                       // material records per field: miss + NS objects
-    __shared__ float4   s_mat[4 * R];               // field f of object k at [f*R + k + 1]; [f*R] = miss
-    __shared__ uint32_t s_next[BLOCK];              // per pixel: next global sample index not started
-    __shared__ float4   s_pix[BLOCK * 3];           // per pixel: (P0, record offset), (colour0, e0), (d0, -)
-    __shared__ float    s_acc[BLOCK * 3];           // per pixel: radiance gathered in phase 2
-    __shared__ unsigned long long s_segs;           // the workgroup's segment count
-    const int tid = threadIdx.x;
-    if (tid == 0) s_segs = 0;
-    if (tid < 4 * R) {
-        const int f = tid / R, r = tid - f * R;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (r > 0 && r - 1 < a.n_obj) {
-            v = a.mat[(r - 1) * 4 + f];
-            if (f == 0) v.w = v.w > 0.f ? v.w : (v.w < 0.f ? -2.f : -1.f);   // light e | diffuse -1 | reflective -2
-        }
-        s_mat[tid] = v;                             // miss record: colour 0, tag 0
-    }
-    auto matp = [&](int p, int f) -> float4 {       // p = 16*(k+1): byte offset of the record within a field
-        return *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s_mat) + p + f * R * 16);
-    };
-    {   // -n_raw and A to VGPRs (see the header comment; negated so that A - o.n_raw is one fma chain)
-        auto fv = [](float &x) { x = __uint_as_float(to_vgpr(__float_as_uint(x))); };
-#pragma unroll
-        for (int k = 0; k < NS; ++k) {
-            sg.g[k][0].x = -sg.g[k][0].x; sg.g[k][0].y = -sg.g[k][0].y; sg.g[k][0].z = -sg.g[k][0].z;
-            fv(sg.g[k][0].x); fv(sg.g[k][0].y); fv(sg.g[k][0].z); fv(sg.g[k][0].w);
-        }
-    }
-
-    const int wbase = tid & ~63;
-    const int npix = a.height * a.width;
-    const int pixel0 = blockIdx.x * BLOCK;
-    const bool in_canvas = pixel0 + tid < npix;
-    const int pc = in_canvas ? pixel0 + tid : 0;
-    const int pi = pc / a.width, pj = pc - pi * a.width;
-    const uint32_t B = (uint32_t)a.max_bounces;
-    const uint32_t Bm1 = B - 1u;                    // 1 <= maxBounces (pt_create): the depth cap as one compare
-    const uint32_t stride = a.sample_stride;
-    // this workgroup's slice of the launch's samples (TraceArgs); slices beyond the first start their sums at 0
-    // in a plane of their own
-    const int slice = blockIdx.y;
-    const int n_samples = a.slice_n[slice];
-    const uint32_t sample_begin = a.sample_begin + (uint32_t)a.slice_j0[slice] * stride;
-    float *const canvas = slice == 0 ? a.canvas : a.partial + (size_t)(slice - 1) * npix * 3;
-    const bool fresh = slice == 0 ? a.fresh != 0 : true;
-    const uint32_t gs_end = sample_begin + (uint32_t)n_samples * stride;   // first sample index beyond this slice
-    const uint32_t ctr_end = gs_end << 6;
-
-    // the fp64 primary search below is counted once, by the launch that executes it
-    unsigned long long segs = in_canvas && slice == 0 && !a.pix_valid ? 1 : 0;
-    f3 acc = mk3(0.f, 0.f, 0.f);
-    if (in_canvas && !fresh) acc = mk3(canvas[3 * (size_t)pc + 0], canvas[3 * (size_t)pc + 1], canvas[3 * (size_t)pc + 2]);
-
-    // primary segment, once per pixel, fp64 (src/Lib.hs:41-51, :81-98); the same for every launch of this
-    // camera and scene, so the first launch leaves it in a.pix for the later ones
-    f3 cd0, cP0;
-    int cidxp;
-    if (a.pix_valid) {
-        const float4 q0 = a.pix[2 * (size_t)pc], q1 = a.pix[2 * (size_t)pc + 1];
-        cP0 = mk3(q0.x, q0.y, q0.z); cd0 = mk3(q0.w, q1.x, q1.y); cidxp = __float_as_int(q1.z);
-    } else {
-        const PrimaryHit ph = primary_hit(a, pi, pj);
-        cd0 = mk3((float)ph.dx, (float)ph.dy, (float)ph.dz);
-        cP0 = mk3((float)(ph.t * ph.dx), (float)(ph.t * ph.dy), (float)(ph.t * ph.dz));
-        cidxp = 16 * (ph.idx + 1);
-        if (a.pix && in_canvas && slice == 0) {
-            a.pix[2 * (size_t)pc] = make_float4(cP0.x, cP0.y, cP0.z, cd0.x);
-            a.pix[2 * (size_t)pc + 1] = make_float4(cd0.y, cd0.z, __int_as_float(cidxp), 0.f);
-        }
-    }
-    f3 ccol = mk3(1.f, 1.f, 1.f);
-    float ce = 0.f;
-    bool traced = in_canvas && cidxp != 0 && B >= 2;      // else every sample is black (src/Lib.hs:68,72)
-    __syncthreads();                                       // s_mat is staged
-    if (in_canvas && cidxp != 0) {
-        const float4 m0 = matp(cidxp, 0);
-        ce = m0.w; ccol = mk3(m0.x, m0.y, m0.z);
-        if (ce > 0.f) {                                    // the primary ray sees a light (src/Lib.hs:74)
-            for (int s = 0; s < n_samples; ++s) { acc.x += ce; acc.y += ce; acc.z += ce; }
-            traced = false;
-        }
-    }
-    s_pix[tid * 3 + 0] = make_float4(cP0.x, cP0.y, cP0.z, __int_as_float(cidxp));
-    s_pix[tid * 3 + 1] = make_float4(ccol.x, ccol.y, ccol.z, ce);
-    s_pix[tid * 3 + 2] = make_float4(cd0.x, cd0.y, cd0.z, 0.f);
-    // LDS byte address of the current pixel's restart record (MASKS: read under exec at every restart, so that
-    // the seven constants do not occupy registers through the loop -- 8 waves per SIMD instead of 7)
-    uint32_t raddr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)&s_pix[tid * 3];
-
-    uint64_t pre = (uint64_t)0xD256D193u * (uint64_t)(uint32_t)pc;
-    f3 o = cP0, d = cd0, thr = ccol;
-    int lastp = cidxp;
-    // lane masks of "the primary object is k" and "the last-struck object is k" (closest_static, MASKS)
-    constexpr bool MASKS = NS <= 4;
-    unsigned long long prim_is[NS], excl[NS];
-    auto primary_masks = [&]() {
-#pragma unroll
-        for (int k = 0; k < NS; ++k) prim_is[k] = __builtin_amdgcn_ballot_w64(cidxp == 16 * (k + 1));
-    };
-    primary_masks();
-#pragma unroll
-    for (int k = 0; k < NS; ++k) excl[k] = prim_is[k];
-    uint32_t ctr = (sample_begin << 6) | 1u;               // (global sample << 6) | segments searched on this path
-    bool alive = traced;                                   // has a path in flight
-    const PhiloxRegs pregs = philox_regs(a.seed);
-
-    auto scatter = [&](int idxp, float e, f3 din, uint32_t c1, f3 at) -> f3 {
-        uint32_t r0, r1;
-        philox2x32_10_pre_v((uint32_t)(pre >> 32), (uint32_t)pre, c1, pregs, r0, r1);
-        if constexpr (SPEC) {
-            const float4 m3 = matp(idxp, 3);
-            f3 nrm = mk3(m3.y, m3.z, m3.w);
-            const bool sphere = m3.x != m3.x;              // NaN marks the Sphere extension: normal at the hit point
-            if (sphere) {
-                const float4 m1 = matp(idxp, 1);
-                nrm = mk3((at.x - m1.x) * m1.w, (at.y - m1.y) * m1.w, (at.z - m1.z) * m1.w);
-            }
-            if (e < -1.5f)                                 // _reflective (src/Lib.hs:110)
-                return scatter_specular(din, nrm, u_theta(r0), u_phi(r1), NOISE_REV);
-            if (sphere) return scatter_diffuse_about(nrm, r0, r1);
-        }
-        return scatter_diffuse_bits(matp(idxp, 1), matp(idxp, 2), matp(idxp, 3).x, r0, r1);   // src/Lib.hs:111
-    };
-    // One segment.  `draw(terminal, c1, c1r)` decides what a finished path does next
-    // and returns in c1r the counter word (sample << 6 | 0) of a restarted path.
-    auto trip = [&](auto all_alive, auto &&draw) {
-        int kp; float t;
-        unsigned long long okm[NS];
-        closest_static<NS, SPEC, MASKS>(sg, a.rect, o, d, lastp, excl, okm, kp, t);
-        const bool live = decltype(all_alive)::value ? true : alive;
-        if (!decltype(all_alive)::value) segs += live ? 1 : 0;            // phase 1 counts its trips wave-uniformly
-        const float4 m0 = matp(kp, 0);
-        // miss (tag 0, src/Lib.hs:72), light (tag e > 0, :74) or the depth cap (:68) end the path
-        bool terminal;
-        unsigned long long tm = 0;
-        if constexpr (MASKS) {                             // the same decision as a lane mask (see below)
-            tm = __builtin_amdgcn_ballot_w64(m0.w >= 0.f) | __builtin_amdgcn_ballot_w64((ctr & 63u) >= Bm1);
-            if (!decltype(all_alive)::value) tm &= __builtin_amdgcn_ballot_w64(live);
-            terminal = __builtin_amdgcn_inverse_ballot_w64(tm);
-        } else {
-            terminal = live && ((m0.w >= 0.f) || ((ctr & 63u) >= Bm1));
-        }
-        {                                                  // emittance * pixel (src/Lib.hs:74); max(tag, 0) is 0 unless a light
-            float E = __int_as_float(max(__float_as_int(m0.w), 0));
-            if (!decltype(all_alive)::value) E = live ? E : 0.f;
-            acc.x = fmaf(E, thr.x, acc.x);
-            acc.y = fmaf(E, thr.y, acc.y);
-            acc.z = fmaf(E, thr.z, acc.z);
-        }
-        uint32_t c1 = ctr, c1r = ctr;
-        draw(terminal, c1, c1r);                           // may clear or set `terminal` (= restart from cP0)
-        if constexpr (MASKS) {
-            if (!decltype(all_alive)::value) tm = __builtin_amdgcn_ballot_w64(terminal);   // phase 2's draw rewrites it
-        }
-        int idxp; float e; f3 din, hp;
-        if constexpr (MASKS) {
-            // The continuing path's values for every lane, then the restart values read in under the lane
-            // mask from the pixel's LDS record: two ds_read_b128 and one v_mov_b32 where selects would be eight
-            // v_cndmask_b32 (second-port class; tools/ubench_issue.hip) from seven registers held through the loop
-            typedef float f4 __attribute__((ext_vector_type(4)));
-            f4 H = {fmaf(t, d.x, o.x), fmaf(t, d.y, o.y), fmaf(t, d.z, o.z), __int_as_float(kp)};   // march (src/Object.hs:151-153)
-            f4 T = {thr.x * m0.x, thr.y * m0.y, thr.z * m0.z, m0.w};                                // pixel * color (src/Lib.hs:79)
-            unsigned long long saved;
-            if constexpr (SPEC) {                          // the specular bounce also reads the incoming direction
-                f4 D = {d.x, d.y, d.z, 0.f};
-                asm volatile("s_and_saveexec_b64 %[sv], %[m]\n\t"
-                             "ds_read_b128 %[H], %[ad]\n\t"
-                             "ds_read_b128 %[T], %[ad] offset:16\n\t"
-                             "ds_read_b128 %[D], %[ad] offset:32\n\t"
-                             "v_mov_b32 %[c], %[cr]\n\t"
-                             "s_waitcnt lgkmcnt(0)\n\t"
-                             "s_mov_b64 exec, %[sv]"
-                             : [H] "+v"(H), [T] "+v"(T), [D] "+v"(D), [c] "+v"(c1), [sv] "=&s"(saved)
-                             : [m] "s"(tm), [ad] "v"(raddr), [cr] "v"(c1r) : "memory");
-                din = mk3(D.x, D.y, D.z);
-                thr = mk3(T.x, T.y, T.z); e = T.w;
-            } else {
-                // (the diffuse bounce does not read the tag: a 96-bit read straight into the throughput's registers;
-                // with the tag as a fourth element hipcc formed the tuple elsewhere and copied it back, 3 v_mov)
-                typedef float f3v __attribute__((ext_vector_type(3)));
-                f3v T3 = {thr.x * m0.x, thr.y * m0.y, thr.z * m0.z};
-                asm volatile("s_and_saveexec_b64 %[sv], %[m]\n\t"
-                             "ds_read_b128 %[H], %[ad]\n\t"
-                             "ds_read_b96 %[T], %[ad] offset:16\n\t"
-                             "v_mov_b32 %[c], %[cr]\n\t"
-                             "s_waitcnt lgkmcnt(0)\n\t"
-                             "s_mov_b64 exec, %[sv]"
-                             : [H] "+v"(H), [T] "+v"(T3), [c] "+v"(c1), [sv] "=&s"(saved)
-                             : [m] "s"(tm), [ad] "v"(raddr), [cr] "v"(c1r) : "memory");
-                din = d;
-                thr = mk3(T3.x, T3.y, T3.z); e = m0.w;
-            }
-            hp = mk3(H.x, H.y, H.z); idxp = __float_as_int(H.w);
-        } else {
-            c1 = terminal ? c1r : c1;
-            idxp = terminal ? cidxp : kp;
-            e    = terminal ? ce : m0.w;
-            din  = terminal ? cd0 : d;
-            hp = mk3(terminal ? cP0.x : fmaf(t, d.x, o.x),                        // march (src/Object.hs:151-153)
-                     terminal ? cP0.y : fmaf(t, d.y, o.y),
-                     terminal ? cP0.z : fmaf(t, d.z, o.z));
-            thr = mk3(terminal ? ccol.x : thr.x * m0.x,                            // pixel * color (src/Lib.hs:79)
-                      terminal ? ccol.y : thr.y * m0.y,
-                      terminal ? ccol.z : thr.z * m0.z);
-        }
-        d = scatter(idxp, e, din, c1, hp);
-        o = hp; lastp = idxp; ctr = c1 + 1u;
-        if constexpr (MASKS) {
-            // next trip's _lastStruck masks: the primary object where the path restarts, else this
-            // trip's winner = the LAST object that was accepted
-            unsigned long long later = 0;
-#pragma unroll
-            for (int k = NS - 1; k >= 0; --k) {
-                const unsigned long long won = okm[k] & ~later;
-                later |= okm[k];
-                excl[k] = (tm & prim_is[k]) | (won & ~tm);
-            }
-        }
-    };
-
-    if (alive) d = scatter(cidxp, ce, cd0, ctr - 1u, cP0);
-
-    // ---- phase 1: every lane on its own pixel --------------------------------
-    const unsigned long long everyone = __ballot(true);
-    const uint32_t next_sample = (stride << 6) - 63u;      // (ctr | 63) + next_sample = (sample + stride) << 6
-    if (__ballot(alive) == everyone) {
-        uint32_t trips = 0;                                // wave-uniform
-        do {
-            trip(std::true_type{}, [&](bool &terminal, uint32_t &c1, uint32_t &c1r) {
-                c1r = (c1 | 63u) + next_sample;
-            });
-            alive = ctr < ctr_end;                         // the sample the lane is on belongs to this launch
-            trips += 1;
-        } while (__ballot(alive) == everyone);
-        segs += trips;
-    }
-    // A lane that has just left phase 1 restarted a path that does not exist
-    // (its sample index is gs_end); it enters phase 2 pathless.
-
-    // ---- phase 2: the wave shares what is left -------------------------------
-    s_next[tid] = alive ? (ctr >> 6) + stride : gs_end;
-    s_acc[tid * 3 + 0] = 0.f; s_acc[tid * 3 + 1] = 0.f; s_acc[tid * 3 + 2] = 0.f;
-    __syncthreads();
-    int cur = tid;                                         // the pixel (workgroup-relative) this lane works on
-    bool dry = false;                                      // wave-uniform: no pixel has an unstarted sample
-    if (__ballot(alive) != 0ull || !dry) do {
-        trip(std::false_type{}, [&](bool &terminal, uint32_t &c1, uint32_t &c1r) {
-            uint32_t g = gs_end;
-            if (terminal) g = atomicAdd(&s_next[cur], stride);           // next sample of my current pixel
-            const bool want = terminal || !alive;          // lanes that need a (new) path
-            bool needy = want && !(terminal && g < gs_end);
-            const bool adopting = !dry && __ballot(needy) != 0ull;
-            while (!dry && __ballot(needy) != 0ull) {
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-                const bool has = __hip_atomic_load(&s_next[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < gs_end;
-                const unsigned long long avail = __ballot(has);      // pixels of this wave with unstarted samples
-                if (avail == 0ull) { dry = true; break; }
-                const int v = wbase + (__ffsll((long long)avail) - 1);   // wave-uniform choice of pixel to help
-                if (needy) {
-                    g = atomicAdd(&s_next[v], stride);
-                    if (g < gs_end) {
-                        if (v != cur) {                    // hand over what was gathered, adopt pixel v
-                            atomicAdd(&s_acc[cur * 3 + 0], acc.x);
-                            atomicAdd(&s_acc[cur * 3 + 1], acc.y);
-                            atomicAdd(&s_acc[cur * 3 + 2], acc.z);
-                            acc = mk3(0.f, 0.f, 0.f);
-                            cur = v;
-                            raddr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)&s_pix[v * 3];
-                            const float4 p0 = s_pix[v * 3 + 0];
-                            cidxp = __float_as_int(p0.w);
-                            if constexpr (!MASKS) {        // the select form keeps the restart constants in registers
-                                const float4 p1 = s_pix[v * 3 + 1], p2 = s_pix[v * 3 + 2];
-                                cP0 = mk3(p0.x, p0.y, p0.z); ccol = mk3(p1.x, p1.y, p1.z); ce = p1.w;
-                                cd0 = mk3(p2.x, p2.y, p2.z);
-                            }
-                            pre = (uint64_t)0xD256D193u * (uint64_t)(uint32_t)(pixel0 + v);
-                        }
-                        needy = false;
-                    }
-                }
-            }
-            if (MASKS && adopting) primary_masks();        // lanes may have moved to another pixel
-            alive = !want || !needy;                       // path continues, or a sample was drawn
-            terminal = want && !needy;                     // restart from the (current) pixel's primary hit
-            c1r = g << 6;
-        });
-    } while (__ballot(alive) != 0ull || !dry);
-
-    atomicAdd(&s_acc[cur * 3 + 0], acc.x);
-    atomicAdd(&s_acc[cur * 3 + 1], acc.y);
-    atomicAdd(&s_acc[cur * 3 + 2], acc.z);
-    // one global atomic per workgroup for the segment counter: 32,400 same-address
-    // atomics (one per wave) serialise in L2 when a short launch's workgroups
-    // retire together
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) segs += __shfl_down(segs, off, 64);
-    if ((tid & 63) == 0 && segs) atomicAdd(&s_segs, segs);
-    __syncthreads();
-    if (in_canvas) {
-        canvas[3 * (size_t)pc + 0] = s_acc[tid * 3 + 0];
-        canvas[3 * (size_t)pc + 1] = s_acc[tid * 3 + 1];
-        canvas[3 * (size_t)pc + 2] = s_acc[tid * 3 + 2];
-    }
-    if (tid == 0 && s_segs) atomicAdd(seg_lane(a.segments), s_segs);
-}
 
 // canvas += plane 0 + plane 1 + ... (in this order): the sample slices of one launch
 __global__ __launch_bounds__(256) void slice_sum_kernel(float4 *__restrict__ canvas, const float4 *__restrict__ partial,
@@ -1333,7 +905,7 @@ __global__ __launch_bounds__(256) void slice_sum_kernel(float4 *__restrict__ can
 
 template <int NS>
 static hipError_t launch_trace_ns(TraceArgs a, const float4 *geom_host, bool reuse, bool spec, bool steal,
-                                  hipStream_t s)
+                                  hipStream_t s, hipFunction_t scene_kernel = nullptr)
 {
     // pad the by-value object list to NS with records that never pass the
     // 0 < t < Inf guard (n = 0 gives t = NaN)
@@ -1367,9 +939,15 @@ static hipError_t launch_trace_ns(TraceArgs a, const float4 *geom_host, bool reu
                 a.slice_n[1] = n / 16; a.slice_n[0] = n - a.slice_n[1]; a.slice_j0[1] = a.slice_n[0];
             }
             const dim3 sgrid((npix + STATIC_BLOCK - 1) / STATIC_BLOCK, a.n_slices), sblock(STATIC_BLOCK);
-            if (spec) hipLaunchKernelGGL((trace_static_kernel<NS, true>), sgrid, sblock, 0, s, a, sg);
-            else      hipLaunchKernelGGL((trace_static_kernel<NS, false>), sgrid, sblock, 0, s, a, sg);
-            hipError_t e = hipGetLastError();
+            hipError_t e;
+            if (scene_kernel) {                                // the same kernel compiled for this scene (pt_jit.hip)
+                void *params[] = {&a, &sg};
+                e = hipModuleLaunchKernel(scene_kernel, sgrid.x, sgrid.y, 1, STATIC_BLOCK, 1, 1, 0, s, params, nullptr);
+            } else {
+                if (spec) hipLaunchKernelGGL((trace_static_kernel<NS, true>), sgrid, sblock, 0, s, a, sg);
+                else      hipLaunchKernelGGL((trace_static_kernel<NS, false>), sgrid, sblock, 0, s, a, sg);
+                e = hipGetLastError();
+            }
             if (e == hipSuccess && a.n_slices > 1) {
                 const size_t n4 = (size_t)npix * 3 / 4;
                 hipLaunchKernelGGL(slice_sum_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s,
@@ -1406,10 +984,11 @@ static hipError_t launch_trace_ns(TraceArgs a, const float4 *geom_host, bool reu
 }
 
 hipError_t launch_trace(const TraceArgs &a, const float4 *geom_host, bool reuse, bool spec, bool lds_tiles,
-                        bool steal, hipStream_t s)
+                        bool steal, hipStream_t s, hipFunction_t scene_kernel)
 {
-    if (a.n_obj <= 4) return launch_trace_ns<4>(a, geom_host, reuse, spec, steal, s);
-    if (a.n_obj <= MAX_STATIC_OBJECTS) return launch_trace_ns<MAX_STATIC_OBJECTS>(a, geom_host, reuse, spec, steal, s);
+    if (a.n_obj <= 4) return launch_trace_ns<4>(a, geom_host, reuse, spec, steal, s, scene_kernel);
+    if (a.n_obj <= MAX_STATIC_OBJECTS)
+        return launch_trace_ns<MAX_STATIC_OBJECTS>(a, geom_host, reuse, spec, steal, s, scene_kernel);
     if (lds_tiles) return launch_trace_ns<-1>(a, geom_host, reuse, spec, false, s);
     if (a.n_nodes > 0) return launch_trace_ns<-2>(a, geom_host, reuse, spec, steal, s);
     return launch_trace_ns<0>(a, geom_host, reuse, spec, steal, s);

@@ -129,6 +129,19 @@ class Renderer:
         """pt_rgb8_device on a caller-named stream (the caller orders it)."""
         check(lib.pt_rgb8_device_on(self._ctx, C.c_void_p(d_out), mode, samples, C.c_void_p(hip_stream)), self._ctx)
 
+    def specialise(self) -> bool:
+        """pt_scene_specialise: compile the trace kernel for this scene (seconds; worth it for a scene that is
+        traced for a while).  True if the scene kernel is now in use, False if the library reported that the
+        step is not available (the general kernel stays in use; `last_error` says why)."""
+        s = lib.pt_scene_specialise(self._ctx)
+        if s == _lib.PT_ERR_UNSUPPORTED:
+            return False
+        check(s, self._ctx)
+        return True
+
+    def last_error(self) -> str:
+        return (lib.pt_last_error(self._ctx) or b"").decode(errors="replace")
+
     def set_timing(self, on: bool = True):
         check(lib.pt_set_timing(self._ctx, 1 if on else 0), self._ctx)
 

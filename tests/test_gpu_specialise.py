@@ -1,0 +1,92 @@
+"""pt_scene_specialise (include/pt.h): trace_static_kernel compiled at run time
+for one scene, zero-coefficient terms left out.  No counterpart in the
+reference; the bar is the library's own general kernel, bit for bit -- same
+canvas, same segment count -- on the default scene (all four objects along the
+axes: every test shortened) and on scenes with general normals, mirrors,
+spheres, rectangles and 5..8 objects (little or nothing to leave out)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pa():
+    import pathtracer_amd
+    return pathtracer_amd
+
+
+def _render(pa, P, objs, spp, specialise, launches=1, **kw):
+    with pa.Renderer(P, objs, seed=3, **kw) as r:
+        if specialise:
+            assert r.specialise(), r.last_error()
+        for _ in range(launches):
+            r.trace(spp)
+        return r.read_sum_f32(), r.segments
+
+
+def _mixed(pa, n):
+    """n <= 8 objects: axis walls, tilted planes and disks, a mirror, a sphere, a rectangle, a lamp."""
+    o = [pa.Object((1, 1, 1), 0, False, pa.InfinitePlane((0, 0, 100), (0, 0, -1)), "back wall"),
+         pa.Object((1, 1, 1), 2.5, True, pa.Disk((0, 0, -1), (0, 0, 1), 25), "lamp"),
+         pa.Object((0.9, 0.4, 0.3), 0, False, pa.InfinitePlane((0, -30, 0), (0.2, 1, 0.1)), "tilted wall"),
+         pa.Object((0.8, 0.8, 1), 0, True, pa.Disk((5, 10, 70), (0.3, -0.4, -1), 30), "mirror disk"),
+         pa.Object((0.3, 0.9, 0.4), 0, False, pa.Sphere((-10.0, -5.0, 60.0), 8.0), "ball"),
+         pa.Object((0.9, 0.9, 0.2), 0, False, pa.Rectangle((25, 0, 60), (-1, 0, 0), 60, 40), "card"),
+         pa.Object((1, 1, 1), 0, False, pa.InfinitePlane((0, 40, 0), (0, -2, 0)), "wall, normal of length 2"),
+         pa.Object((0.5, 0.5, 0.5), 0, True, pa.InfinitePlane((-30, 0, 0), (1, 0, 0)), "mirror floor")]
+    return o[:n]
+
+
+def test_default_scene_bit_for_bit(pa):
+    P = pa.Params(200, 136, 500.0, 1, 8)
+    a, sa = _render(pa, P, pa.objects, 96, False)
+    b, sb = _render(pa, P, pa.objects, 96, True)
+    assert sa == sb and sa > 200 * 136 * 96
+    assert np.array_equal(a, b)
+    assert a.sum() > 0
+
+
+@pytest.mark.parametrize("n", [2, 3, 4, 5, 6, 7, 8])
+def test_mixed_scenes_bit_for_bit(pa, n):
+    P = pa.Params(120, 150, 90.0, 1, 6)
+    objs = _mixed(pa, n)
+    a, sa = _render(pa, P, objs, 48, False)
+    b, sb = _render(pa, P, objs, 48, True)
+    assert sa == sb
+    assert np.array_equal(a, b)
+    assert a.sum() > 0
+
+
+def test_sliced_and_repeated_launches(pa):
+    """>= 512 samples: the launch runs as two sample slices; then a second launch that reads the kept primary hits."""
+    P = pa.Params(64, 128, 500.0, 1, 8)
+    a, sa = _render(pa, P, pa.objects, 520, False, launches=2)
+    b, sb = _render(pa, P, pa.objects, 520, True, launches=2)
+    assert sa == sb
+    assert np.array_equal(a, b)
+
+
+def test_a_new_scene_drops_the_kernel(pa):
+    P = pa.Params(64, 64, 90.0, 1, 5)
+    ref, _ = _render(pa, P, _mixed(pa, 4), 32, False)
+    with pa.Renderer(P, pa.objects, seed=3) as r:
+        assert r.specialise()
+        r.upload(_mixed(pa, 4))              # the default scene's kernel must not trace this one
+        r.trace(32)
+        assert np.array_equal(r.read_sum_f32(), ref)
+        assert r.specialise()                # and the new scene can have its own
+        r.reset()
+        r.trace(32)
+        assert np.array_equal(r.read_sum_f32(), ref)
+
+
+def test_where_it_does_not_apply(pa):
+    P = pa.Params(32, 32, 90.0, 1, 4)
+    with pa.Renderer(P, pa.random_disk_scene(40, 1)) as r:      # not a by-value scene
+        assert not r.specialise()
+        assert "8 objects" in r.last_error()
+        r.trace(4)
+    with pa.Renderer(P, pa.objects, flags=pa.PT_FLAG_NO_STEAL) as r:
+        assert not r.specialise()
+        r.trace(4)
