@@ -230,7 +230,9 @@ int pt_dev_philox(pt_ctx *ctx, int32_t n, const uint32_t *c0, const uint32_t *c1
  * meant for a scene that will be traced for a while.  Applies to scenes of
  * <= 8 objects on the default flags; the kernel is dropped by the next
  * pt_scene_upload.  On PT_ERR_UNSUPPORTED (no libhiprtc on the machine, a scene
- * or flags it does not cover) the context keeps using the general kernel. */
+ * or flags it does not cover) the context keeps using the general kernel.
+ * PT_SPECIALISE=1 in the environment makes pt_scene_upload do this for every
+ * scene it applies to (failures ignored). */
 int pt_scene_specialise(pt_ctx *ctx);
 
 /* Last kernel's launch duration in milliseconds, measured with HIP events on

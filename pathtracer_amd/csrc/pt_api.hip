@@ -9,6 +9,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <new>
@@ -392,6 +393,14 @@ int pt_scene_upload(pt_ctx *c, const pt_object *objs, int32_t n)
             PT_HIP(c, hipMemcpy(c->d_bvh_geom, lg.data(), lg.size() * sizeof(float4), hipMemcpyHostToDevice));
             c->n_nodes = (int)bvh.nodes.size();
             c->n_unbounded = bvh.n_unbounded;
+        }
+    }
+    // PT_SPECIALISE=1 in the environment: pt_scene_specialise for every scene it applies to (how the whole GPU
+    // test suite is run against the scene kernels); where it does not apply the general kernel stays, silently
+    if (const char *e = getenv("PT_SPECIALISE")) {
+        if (e[0] == '1' && c->n_obj <= MAX_STATIC_OBJECTS && !(c->p.flags & (PT_FLAG_NO_STEAL | PT_FLAG_NO_PRIMARY_REUSE))) {
+            std::string why;
+            c->scene_kernel = jit_static_kernel(c->p.device, c->n_obj, c->has_specular, c->h_geom.data(), why);
         }
     }
     return PT_OK;
