@@ -156,6 +156,9 @@ __device__ __forceinline__ void closest_static(const StaticGeom<NS> &sg, const f
     // unchanged by the rounding.  A strict '<' keeps the earlier object on ties.
     uint32_t best_key = 0x7f800000u;
     bestp = 0;
+#ifdef PT_JIT
+    float rdens[NS];
+#endif
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
 #ifdef PT_JIT
@@ -173,12 +176,33 @@ __device__ __forceinline__ void closest_static(const StaticGeom<NS> &sg, const f
         // zero is not computed -- adding its +-0 would not change the sum --, a coefficient of +-1 is a sign,
         // and the plane/disk/sphere choice below is decided by the compiler.  Same roundings as the general form.
         const float num = jit_chain(g0.w, c0.x, o.x, g0.x, c0.y, o.y, g0.y, c0.z, o.z, g0.z);
-        const float den = jit_dot(g1.x, v.x, g1.y, v.y, g1.z, v.z);
 #else
         const float num = fmaf(o.z, g0.z, fmaf(o.y, g0.y, fmaf(o.x, g0.x, g0.w)));
         const float den = fmaf(v.z, g1.z, fmaf(v.y, g1.y, v.x * g1.x));
 #endif
+#ifdef PT_JIT
+        // The reciprocal is taken of v.(+-n_hat), the sign chosen so that the first non-zero coefficient is positive,
+        // and the sign goes on the numerator (a free source modifier of the fma; v_rcp_f32 is odd in its argument
+        // and every rounding is symmetric in sign, so t has the same bits).  An earlier object with the same or
+        // the opposite unit normal (facing walls; the default scene's back wall and its light) then has the very
+        // same denominator, and its reciprocal serves: one quarter-rate instruction less.
+        // (Written as -(1/den), hipcc folds the negation into the reciprocal's operand and issues a second v_rcp_f32.)
+        const bool flipped = g1.x < 0.0f || (g1.x == 0.0f && (g1.y < 0.0f || (g1.y == 0.0f && g1.z < 0.0f)));
+        const float ux = flipped ? -g1.x : g1.x, uy = flipped ? -g1.y : g1.y, uz = flipped ? -g1.z : g1.z;
+        int shared = -1;
+#pragma unroll
+        for (int j = 0; j < k; ++j) {
+            const bool same = JIT_GEOM[j][4] == g1.x && JIT_GEOM[j][5] == g1.y && JIT_GEOM[j][6] == g1.z;
+            const bool opposite = JIT_GEOM[j][4] == -g1.x && JIT_GEOM[j][5] == -g1.y && JIT_GEOM[j][6] == -g1.z;
+            const bool real = g1.x != 0.0f || g1.y != 0.0f || g1.z != 0.0f;       // (not a padding record)
+            if (shared < 0 && real && (same || opposite)) shared = j;
+        }
+        const float rden = shared < 0 ? __builtin_amdgcn_rcpf(jit_dot(ux, v.x, uy, v.y, uz, v.z)) : rdens[shared];
+        rdens[k] = rden;
+        float t = flipped ? fmaf(-num, rden, -__builtin_bit_cast(float, 1u)) : fmaf(num, rden, -__builtin_bit_cast(float, 1u));
+#else
         float t = fmaf(num, __builtin_amdgcn_rcpf(den), -__builtin_bit_cast(float, 1u));
+#endif
         if constexpr (SPH) {
             if (g1.w < 0.0f)                                       // wave-uniform: Sphere (extension)
                 t = fmaf(sphere_t(mk3(g2.x, g2.y, g2.z), -g1.w, o, v), 1.0f, -__builtin_bit_cast(float, 1u));

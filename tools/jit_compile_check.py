@@ -42,5 +42,6 @@ if rc == 0:
     code = C.create_string_buffer(n.value)
     rtc.hiprtcGetCode(prog, code)
     open("/tmp/pt_scene_kernel.co", "wb").write(code.raw)
-    os.system("/opt/rocm/lib/llvm/bin/llvm-readelf --notes /tmp/pt_scene_kernel.co | grep -E 'vgpr_count|sgpr_count|spill'")
+    os.system("/opt/rocm/lib/llvm/bin/llvm-objdump -d /tmp/pt_scene_kernel.co | grep -c v_rcp_f32 | sed 's/^/v_rcp_f32 in the code object: /'")
+    os.system("/opt/rocm/lib/llvm/bin/llvm-readelf --notes /tmp/pt_scene_kernel.co | grep -E 'vgpr_count|sgpr_count|spill|private_segment_fixed'")
 sys.exit(rc)
