@@ -72,6 +72,7 @@ instance Storable PtObject where
 foreign import ccall safe "pt_create"       c_pt_create       :: Ptr (Ptr PtCtx) -> Ptr PtParams -> IO CInt
 foreign import ccall safe "pt_scene_upload" c_pt_scene_upload :: Ptr PtCtx -> Ptr PtObject -> Int32 -> IO CInt
 foreign import ccall safe "pt_trace"        c_pt_trace        :: Ptr PtCtx -> Int32 -> IO CInt
+foreign import ccall safe "pt_scene_specialise" c_pt_scene_specialise :: Ptr PtCtx -> IO CInt
 foreign import ccall safe "pt_read_sum"     c_pt_read_sum     :: Ptr PtCtx -> Ptr Double -> IO CInt
 foreign import ccall safe "pt_last_error"   c_pt_last_error   :: Ptr PtCtx -> IO CString
 foreign import ccall safe "&pt_destroy"     p_pt_destroy      :: FunPtr (Ptr PtCtx -> IO ())
@@ -90,6 +91,9 @@ context = unsafePerformIO $ alloca $ \pp -> with params $ \ppar -> do
   ctx <- peek pp
   withArrayLen (map PtObject (V.toList objects)) $ \n arr ->
     c_pt_scene_upload ctx arr (fromIntegral n) >>= check ctx
+  -- Object.objects is a constant of the program (src/Object.hs:147-148): let the library compile its kernel
+  -- for it.  Optional -- any status but 0 leaves the general kernel in use -- so the result is not checked.
+  _ <- c_pt_scene_specialise ctx
   newForeignPtr p_pt_destroy ctx
   where
     params = PtParams (fromIntegral Params.height) (fromIntegral Params.width) Params.cameraDepth

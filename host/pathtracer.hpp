@@ -137,6 +137,15 @@ public:
             done += n;
         }
     }
+    // pt_scene_specialise: the trace kernel compiled for this scene (seconds once, then faster launches; the
+    // image is the same).  False where the library cannot (no hiprtc, more than 8 objects): nothing changes.
+    bool specialise()
+    {
+        const int s = pt_scene_specialise(ctx_);
+        if (s == PT_ERR_UNSUPPORTED) return false;
+        check(s);
+        return true;
+    }
     uint64_t segments()
     {
         uint64_t s = 0;

@@ -42,6 +42,8 @@ int main(int argc, char **argv)
     try {
         Lib::Traces traces(p, objects(), seed, device);
         const auto t0 = std::chrono::steady_clock::now();
+        if ((int64_t)p.height * p.width * p.numIters >= (int64_t)1 << 26)
+            traces.specialise();                                      // a frame of seconds: worth the second of compilation
         traces.advance(p.numIters);                                   // traces !! Params.numIters
         const Conversion::Image img = Conversion::repa3ToImage(traces, mode);
         const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();

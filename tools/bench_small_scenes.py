@@ -24,6 +24,8 @@ P = pa.Params(1920, 1080, 500.0, 256, 8)
 for name, objs in (("default (4 objects)", pa.objects), ("room, 8 objects, mirror + rectangles", room),
                    ("8 planes and disks, diffuse", disks8)):
     with pa.Renderer(P, objs, seed=0) as r:
+        if "--specialise" in sys.argv:
+            assert r.specialise(), r.last_error()
         r.trace(8); r.synchronize()
         ts = []
         for _ in range(3):
