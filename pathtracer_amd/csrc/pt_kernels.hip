@@ -6,6 +6,9 @@
 //                         arguments): THE hot kernel, the one bench.py times.
 //                         Large launches run as two sample slices of one grid;
 //                         slice_sum_kernel adds the second slice's plane.
+//                         Defined in pt_static_kernel.hpp, which pt_jit.hip
+//                         compiles a second time, at run time, for one scene
+//                         (pt_scene_specialise).
 //   trace_bvh_kernel    : larger scenes searched through the spatial index:
 //                         resumable per-lane searches, the wave alternates walk
 //                         and shade steps.
