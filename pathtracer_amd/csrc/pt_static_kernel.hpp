@@ -229,7 +229,11 @@ __device__ __forceinline__ void closest_static(const StaticGeom<NS> &sg, const f
                 break;
             case 1: take_under<32>(m, bestp, best_key, key); break;
             case 2: take_under<48>(m, bestp, best_key, key); break;
-            default: take_under<64>(m, bestp, best_key, key); break;
+            case 3: take_under<64>(m, bestp, best_key, key); break;
+            case 4: take_under<80>(m, bestp, best_key, key); break;
+            case 5: take_under<96>(m, bestp, best_key, key); break;
+            case 6: take_under<112>(m, bestp, best_key, key); break;
+            default: take_under<128>(m, bestp, best_key, key); break;
             }
         } else {
             bestp = ok ? 16 * (k + 1) : bestp;
@@ -341,7 +345,11 @@ __global__ __launch_bounds__(STATIC_BLOCK) void trace_static_kernel(TraceArgs a,
     f3 o = cP0, d = cd0, thr = ccol;
     int lastp = cidxp;
     // lane masks of "the primary object is k" and "the last-struck object is k" (closest_static, MASKS)
+#ifdef PT_JIT
+    constexpr bool MASKS = true;      // (8 objects too: their geometry is in the code, not in 64 SGPRs, so the masks fit)
+#else
     constexpr bool MASKS = NS <= 4;
+#endif
     unsigned long long prim_is[NS], excl[NS];
     auto primary_masks = [&]() {
 #pragma unroll
