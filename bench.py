@@ -175,7 +175,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(max(args.warmup, 1)):       # at least one, to count a step's segments
+    # at least one untimed step per context (two when frames are double-buffered): a context's first launch
+    # allocates its slice plane and computes and keeps the primary hits, which is set-up, not a step
+    for _ in range(max(args.warmup, len(rs))):
         step()
     fence()
     if pipe is not None:
