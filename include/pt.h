@@ -226,7 +226,8 @@ int pt_dev_philox(pt_ctx *ctx, int32_t n, const uint32_t *c0, const uint32_t *c1
  * are) are not computed.  The arithmetic that remains is the general kernel's
  * rounding for rounding: images agree bit for bit, except that a ray direction
  * with an exactly zero component may see -0 where the general form sees +0.
- * Costs a compilation (seconds; cached per process, scene and device), so it is
+ * Costs a compilation (about a second; cached per process, scene and device --
+ * a compiled kernel, ~16 KB, stays loaded until the process ends), so it is
  * meant for a scene that will be traced for a while.  Applies to scenes of
  * <= 8 objects on the default flags; the kernel is dropped by the next
  * pt_scene_upload.  On PT_ERR_UNSUPPORTED (no libhiprtc on the machine, a scene
