@@ -1,7 +1,7 @@
 // pt_static_kernel.hpp -- trace_static_kernel, the default kernel for scenes
 // of <= 8 objects (object list in the kernel arguments).  A header of its own
 // because it is compiled twice: ahead of time by pt_kernels.hip, for any scene,
-// and at run time by pt_jit.cpp (hiprtc) with PT_JIT defined and ONE scene's
+// and at run time by pt_jit.hip (hiprtc) with PT_JIT defined and ONE scene's
 // geometry as compile-time constants (pt_scene_specialise, include/pt.h).
 #pragma once
 
@@ -70,7 +70,7 @@ __device__ __forceinline__ PrimaryHit primary_hit(const TraceArgs &a, int pi, in
 // best <- (OFF, key) in the lanes of `mask`: two plain-class moves under exec
 // instead of two second-port selects
 #ifdef PT_JIT
-// The scene this translation unit is compiled for (pt_jit.cpp writes the three macros):
+// The scene this translation unit is compiled for (pt_jit.hip writes the three macros):
 // 12 floats per object, (n_raw, A) (n_hat, r^2 | +inf | -r) (centre, 0), padded to PT_JIT_NS like launch_trace_ns pads.
 __device__ constexpr float JIT_GEOM[PT_JIT_NS][12] = PT_JIT_GEOM;
 
