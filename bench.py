@@ -22,7 +22,15 @@ launch, not once per sample (the primary ray has no jitter, src/Lib.hs:41-51),
 and only executed searches are counted.
 
 Usage:  python bench.py [--gpus N] [--steps K] [--warmup W]
-        (N > 1: launched by torch.distributed.run, one rank per GPU)
+N > 1 runs one rank process per GPU.  Under torch.distributed.run the ranks
+exist already (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment);
+typed as plain `python bench.py --gpus N` this process -- before it imports
+torch or touches a GPU -- starts the N rank processes itself (self_launch) and
+relays rank 0's JSON line.  The frame's ONE collective is libpt's own
+ncclAllReduce (pt_comm_init_rank / pt_allreduce_sum, include/pt.h: RCCL behind
+the C ABI); torch.distributed (gloo, CPU) only carries the RCCL id, the barriers
+and the max-over-ranks of the time.  --collective torch times torch's RCCL
+all-reduce on the same canvases instead.
 """
 import argparse
 import json
@@ -46,9 +54,7 @@ def flops_per_segment(objs):
     return f + (sum(scat) / len(scat) if scat else 0)
 
 
-def cpu_baseline(height, width, depth, bounces, threads, target_s=15.0):
-    """The oracle (CPU fp64 restatement of the reference, StdGen stream) timed
-    on this box's host cores on a bounded sample of the same workload."""
+def _time_oracle(height, width, depth, bounces, threads, target_s):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle as O
     p = O.params(height, width, depth, bounces, O.STDGEN)
@@ -62,11 +68,71 @@ def cpu_baseline(height, width, depth, bounces, threads, target_s=15.0):
         tr.trace(more)
         spp += more
     dt = time.perf_counter() - t0
-    return {"value": round(tr.segments.value / dt / 1e6, 3), "unit": "Mrays/s", "cores": threads,
+    return tr.segments.value, spp, dt
+
+
+def cpu_baseline(height, width, depth, bounces, threads, target_s=12.0):
+    """The oracle (CPU fp64 restatement of the reference, StdGen stream) timed
+    on this box's host cores on a bounded sample of the same workload: with
+    `threads` OpenMP threads, and with one (the reference itself
+    never runs in parallel, SURVEY F11, so the single-thread figure is the one
+    closest to what the Haskell program does)."""
+    segs, spp, dt = _time_oracle(height, width, depth, bounces, threads, target_s)
+    segs1, spp1, dt1 = _time_oracle(height, width, depth, bounces, 1, target_s / 2)
+    what = "fp64 C restatement of the reference (oracle/pt_oracle.c, StdGen stream), not the Haskell program"
+    return {"value": round(segs / dt / 1e6, 3), "unit": "Mrays/s", "cores": threads,
             "kind": "port",
             "sample": f"default scene {height}x{width}, {spp} spp, depth {bounces}: "
-                      f"{tr.segments.value} segments in {dt:.2f} s; fp64 C restatement of the reference "
-                      f"(oracle/pt_oracle.c, StdGen stream, OpenMP over rows), not the Haskell program"}
+                      f"{segs} segments in {dt:.2f} s; {what}; OpenMP over rows",
+            "single_thread": {"value": round(segs1 / dt1 / 1e6, 3), "unit": "Mrays/s", "cores": 1,
+                              "sample": f"the same frame, {spp1} spp: {segs1} segments in {dt1:.2f} s"}}
+
+
+def rank_environments(n, port, base=None):
+    """The environment of each of `n` rank processes of one node, as
+    torch.distributed.run would set it (what main() reads)."""
+    base = dict(os.environ if base is None else base)
+    envs = []
+    for r in range(n):
+        e = dict(base)
+        e.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                 MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        envs.append(e)
+    return envs
+
+
+def self_launch(n, argv):
+    """`python bench.py --gpus N` typed as is: start the N rank processes (this
+    same script with the rank environment), relay rank 0's stdout -- the ONE JSON
+    line -- and exit with the worst exit status.  Called before torch is imported
+    or a GPU touched: nothing that initialised a GPU is forked or replaced.  If a
+    rank dies the others are ended (by their own PIDs), not left in a rendezvous."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r, env in enumerate(rank_environments(n, port)):
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr.fileno()))
+    rc = 0
+    pending = set(range(n))
+    while pending:
+        for r in sorted(pending):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            pending.discard(r)
+            if code != 0:
+                rc = rc or code
+                for q in pending:
+                    procs[q].terminate()
+        time.sleep(0.05)
+    out = procs[0].stdout.read().decode(errors="replace")
+    sys.stdout.write(out)
+    sys.stdout.flush()
+    return rc
 
 
 def main():
@@ -91,7 +157,11 @@ def main():
                     help="keep the general trace kernel: no pt_scene_specialise (kernel compiled for the scene) at set-up")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="trace, all-reduce and output strictly in line instead of overlapped with the next frame")
+    ap.add_argument("--collective", choices=("libpt", "torch"), default="libpt",
+                    help="N > 1: libpt's own ncclAllReduce behind the C ABI (default) or torch.distributed's")
     args = ap.parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
     # stdout carries exactly ONE line, the JSON: anything a library prints to file descriptor 1
     # (RCCL's start-up banner does) goes to stderr instead
     json_out = os.fdopen(os.dup(1), "w")
@@ -100,10 +170,19 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
-        args.gpus = world
+    args.gpus = world
+    if os.environ.get("PT_BENCH_DRY_RUN") == "1":
+        # rank bookkeeping only (tests/test_bench_launcher.py, no GPU): rendezvous over gloo, count the ranks
+        import torch
+        import torch.distributed as dist
+        dist.init_process_group("gloo")
+        t = torch.tensor([rank + 1, local_rank + 1], dtype=torch.int64)
+        dist.all_reduce(t)
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": world, "rank_sum": int(t[0]), "local_rank_sum": int(t[1])}),
+                  file=json_out, flush=True)
+        dist.destroy_process_group()
+        return
 
     import torch
     import pathtracer_amd as pa
@@ -113,12 +192,13 @@ def main():
         sys.exit("bench.py needs a GPU: libpt has no CPU path")
     torch.cuda.set_device(local_rank)
     dist = None
-    # PT_BENCH_FORCE_DIST=1 drives the RCCL all-reduce path with a world of 1 (rehearsal on a 1-GPU box)
-    if world > 1 or os.environ.get("PT_BENCH_FORCE_DIST") == "1":
+    # PT_BENCH_FORCE_DIST=1 drives the collective path with a world of 1 (rehearsal on a 1-GPU box)
+    multi = world > 1 or os.environ.get("PT_BENCH_FORCE_DIST") == "1"
+    if multi:
         import torch.distributed as dist
         if "MASTER_ADDR" not in os.environ:
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group("gloo")          # control plane only: the RCCL id, barriers, max of the time
 
     my_spp, s_off, s_stride = shard_samples(args.spp, rank, world)
     P = pa.Params(args.height, args.width, args.camera_depth, args.spp, args.bounces)
@@ -156,8 +236,38 @@ def main():
     canvas = canvases[0]
     rgbs = [torch.empty(args.height * args.width * 3, dtype=torch.uint8, device="cuda") for _ in rs]
     rgb = rgbs[0]
+    # The frame's collective.  libpt: one RCCL communicator per context (frames k and k+1 are in flight together
+    # on two streams), rank 0's id handed round over gloo.  If RCCL cannot be reached through libpt on this
+    # machine every rank falls back to torch's all-reduce together, and the JSON line says which one ran.
+    collective, comm = None, {}
+    if multi:
+        collective = args.collective
+        if collective == "libpt":
+            ok = 1
+            try:
+                for q in rs:
+                    box = [pa.Renderer.comm_unique_id() if rank == 0 else None]
+                    dist.broadcast_object_list(box, src=0)
+                    q.comm_init_rank(box[0], rank, world)
+                comm = rs[0].comm_info()
+            except Exception as e:                      # noqa: BLE001 (reported, then decided by all ranks together)
+                print(f"bench.py: rank {rank}: libpt collective unavailable: {e}", file=sys.stderr)
+                ok = 0
+            flag = torch.tensor([ok], dtype=torch.int64)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0:
+                collective = "torch"
+        if collective == "torch":
+            nccl_group = dist.new_group(backend="nccl")
+
+    def allreduce(q, cv):
+        if collective == "libpt":
+            q.allreduce_sum()                           # ncclAllReduce on the context's stream, into its total
+            return None
+        return dist.all_reduce(cv, op=dist.ReduceOp.SUM, group=nccl_group, async_op=True)
+
     pipe = PipelinedFrames(rs, canvases, rgbs, rank=rank, spp_total=args.spp, my_spp=my_spp,
-                           mode=pa.PT_RGB8_MEAN_CLAMP, dist=dist) if pipelined else None
+                           mode=pa.PT_RGB8_MEAN_CLAMP, allreduce=allreduce if multi else None) if pipelined else None
 
     def step():
         if pipe is not None:
@@ -165,8 +275,10 @@ def main():
             return
         r.reset()
         r.trace(my_spp)
-        if dist is not None:
-            allreduce_canvas(canvas)
+        if multi:
+            work = allreduce(r, canvas)
+            if work is not None:
+                work.wait()
         if rank == 0:
             r.rgb8_device(rgb.data_ptr(), pa.PT_RGB8_MEAN_CLAMP, args.spp)
 
@@ -182,7 +294,7 @@ def main():
     fence()
     if pipe is not None:
         r = rs[(pipe.k - 1) & 1]               # the context of the last frame: its counter holds one step
-    segs_step = torch.tensor([r.segments], dtype=torch.float64, device="cuda")
+    segs_step = torch.tensor([r.segments], dtype=torch.float64)
 
     fence()
     t0 = time.perf_counter()
@@ -202,7 +314,7 @@ def main():
     fence()
     kern_ms = sum(ev) / len(ev) / max(launches, 1)
 
-    t_el = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    t_el = torch.tensor([elapsed], dtype=torch.float64)
     if dist is not None:
         dist.all_reduce(t_el, op=dist.ReduceOp.MAX)
         dist.all_reduce(segs_step, op=dist.ReduceOp.SUM)
@@ -243,8 +355,15 @@ def main():
                        "primary_reuse": not args.no_primary_reuse,
                        "scene_kernel": "compiled for this scene at set-up (pt_scene_specialise)" if specialised
                                        else "general",
-
+                       "scene_kernel_compiler": r.jit_info() if specialised else None,
                        "parallelism": f"sample-split x{world}",
+                       "collective": None if not multi else
+                                     (f"libpt ncclAllReduce behind the C ABI (pt_allreduce_sum), {comm.get('n_ranks')} RCCL ranks, "
+                                      f"RCCL version code {comm.get('rccl_version')}" if collective == "libpt"
+                                      else "torch.distributed all_reduce (nccl = RCCL)"),
+                       "value_mode": "wall time of K pipelined frames (barrier + device synchronize on both sides, "
+                                     "max over ranks); consecutive frames overlap on two streams"
+                                     if pipe is not None else "wall time of K in-line frames",
                        "frame_pipeline": "double-buffered: all-reduce + output of frame k overlap the trace of "
                                          "frame k+1" if pipe is not None else "none"},
             "roofline": {"bound": "valu", "achieved": round(achieved, 3), "peak": FP32_VALU_PEAK_TFLOPS,
@@ -254,6 +373,11 @@ def main():
                                    ("trace_static_kernel" if len(scene) <= 8 else
                                     "trace_bvh_kernel" if indexed else "trace_steal_kernel"),
                          "kernel_ms": round(kern_ms, 4),
+                         "kernel_ms_mode": "serial: a separate pass after the timed steps, one launch at a time, HIP "
+                                           "events on the launch stream (pt_last_trace_ms), rank 0",
+                         "traffic_source": None if traffic is None else
+                                           "profiles/hbm_traffic.json (rocprofv3 PMC passes of an earlier run of this "
+                                           "command, not measured in this run)",
                          "flops_per_segment": F, "segments_per_launch": int(segs_launch_rank0),
                          "note": "fp32 VALU-bound path (no MFMA, ~0 HBM bytes per segment); peak = fp32 vector "
                                  "157.3 TFLOP/s (= the fp32 MFMA peak)"},

@@ -110,6 +110,22 @@ public:
         cp.max_bounces = p.maxBounces; cp.seed = seed; cp.device = device;
         cp.sample_offset = sample_offset; cp.sample_stride = sample_stride; cp.flags = 0;
         check(pt_create(&ctx_, &cp));
+        upload(objs);
+    }
+    // The same `traces` rendered by several GPUs of this process (pt_create_multi, include/pt.h): every
+    // advance() is sharded by sample index over `devices`, every read all-reduced over RCCL inside libpt.
+    Traces(const Params &p, const std::vector<Object> &objs, const std::vector<int32_t> &devices, uint32_t seed = 0)
+        : params_(p)
+    {
+        pt_params cp{};
+        cp.height = p.height; cp.width = p.width; cp.camera_depth = p.cameraDepth;
+        cp.max_bounces = p.maxBounces; cp.seed = seed; cp.device = devices.empty() ? 0 : devices[0];
+        cp.sample_offset = 0; cp.sample_stride = 1; cp.flags = 0;
+        check(pt_create_multi(&ctx_, &cp, devices.data(), (int32_t)devices.size()));
+        upload(objs);
+    }
+    void upload(const std::vector<Object> &objs)
+    {
         std::vector<pt_object> c;
         for (const Object &o : objs) c.push_back(o.to_c());
         check(pt_scene_upload(ctx_, c.data(), (int32_t)c.size()));

@@ -6,12 +6,15 @@
 //
 // usage: write [--height H] [--width W] [--camera-depth D] [--iters N] [--bounces B]
 //              [--seed S] [--mode reference|mean|gamma] [--out image.png] [--device K]
+//              [--gpus N | --devices a,b,c]   several GPUs of this process: the iterations are sharded by
+//                                             sample index and all-reduced over RCCL inside libpt (pt_create_multi)
 #include "pathtracer.hpp"
 
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 
 using namespace pathtracer;
 
@@ -21,6 +24,7 @@ int main(int argc, char **argv)
     std::string out = "image.png";
     uint32_t seed = 0;
     int mode = PT_RGB8_REFERENCE, device = 0;
+    std::vector<int32_t> devices;
     for (int i = 1; i < argc; ++i) {
         auto arg = [&](const char *name) { return !std::strcmp(argv[i], name) && i + 1 < argc; };
         if (arg("--height")) p.height = std::atoi(argv[++i]);
@@ -30,6 +34,11 @@ int main(int argc, char **argv)
         else if (arg("--bounces")) p.maxBounces = std::atoi(argv[++i]);
         else if (arg("--seed")) seed = (uint32_t)std::strtoul(argv[++i], nullptr, 10);
         else if (arg("--device")) device = std::atoi(argv[++i]);
+        else if (arg("--gpus")) { const int n = std::atoi(argv[++i]); devices.clear(); for (int d = 0; d < n; ++d) devices.push_back(d); }
+        else if (arg("--devices")) {
+            devices.clear();
+            for (char *tok = std::strtok(argv[++i], ","); tok; tok = std::strtok(nullptr, ",")) devices.push_back(std::atoi(tok));
+        }
         else if (arg("--out")) out = argv[++i];
         else if (arg("--mode")) {
             const std::string m = argv[++i];
@@ -40,7 +49,9 @@ int main(int argc, char **argv)
         }
     }
     try {
-        Lib::Traces traces(p, objects(), seed, device);
+        std::unique_ptr<Lib::Traces> owner(devices.empty() ? new Lib::Traces(p, objects(), seed, device)
+                                                           : new Lib::Traces(p, objects(), devices, seed));
+        Lib::Traces &traces = *owner;
         const auto t0 = std::chrono::steady_clock::now();
         if ((int64_t)p.height * p.width * p.numIters >= (int64_t)1 << 26)
             traces.specialise();                                      // a frame of seconds: worth the second of compilation
@@ -50,9 +61,9 @@ int main(int argc, char **argv)
         Conversion::savePngImage(out, img);
         const uint64_t segs = traces.segments();
         std::printf("{\"image\": \"%s\", \"width_px\": %d, \"height_px\": %d, \"iters\": %d, \"max_bounces\": %d, "
-                    "\"segments\": %llu, \"render_ms\": %.3f, \"mrays_per_s\": %.1f}\n",
+                    "\"segments\": %llu, \"render_ms\": %.3f, \"mrays_per_s\": %.1f, \"gpus\": %d}\n",
                     out.c_str(), img.width, img.height, p.numIters, p.maxBounces, (unsigned long long)segs, ms,
-                    segs / (ms * 1e3));
+                    segs / (ms * 1e3), devices.empty() ? 1 : (int)devices.size());
     } catch (const std::exception &e) {
         std::fprintf(stderr, "write: %s\n", e.what());
         return 1;

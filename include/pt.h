@@ -15,7 +15,8 @@
  * Conventions: every function returns PT_OK (0) or a negative pt_status and
  * never throws or aborts across the boundary; all buffers are caller-allocated
  * and the library never frees or keeps caller memory; a pt_ctx is bound to one
- * GPU and is not thread-safe, distinct contexts are independent.  There is no
+ * GPU (a pt_create_multi context: to a list of GPUs) and is not thread-safe,
+ * distinct contexts are independent.  There is no
  * CPU fallback: without a usable HIP device pt_create fails with
  * PT_ERR_NO_DEVICE.
  */
@@ -29,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PT_ABI_VERSION 2   /* 2: pt_object gained extent[2] (PT_RECTANGLE) */
+#define PT_ABI_VERSION 3   /* 2: pt_object gained extent[2] (PT_RECTANGLE); 3: multi-GPU entry points */
 
 typedef enum {
     PT_OK             =  0,
@@ -235,12 +236,63 @@ int pt_dev_philox(pt_ctx *ctx, int32_t n, const uint32_t *c0, const uint32_t *c1
  * PT_SPECIALISE=1 in the environment makes pt_scene_upload do this for every
  * scene it applies to (failures ignored). */
 int pt_scene_specialise(pt_ctx *ctx);
+/* Which compiler built the context's scene kernel, as text: hiprtc's version
+ * and file, the target, and whether it had __builtin_amdgcn_inverse_ballot_w64
+ * (a process that loaded PyTorch's bundled ROCm first compiles with that older
+ * hiprtc, which lacks it; the kernel then uses a v_cndmask_b32 form of the
+ * same decision).  Empty when the general kernel is in use. */
+int pt_jit_info(pt_ctx *ctx, char *buf, size_t size);
 
 /* Last kernel's launch duration in milliseconds, measured with HIP events on
  * the context's stream around the most recent pt_trace (all its launches).
  * Enabled by pt_set_timing(ctx, 1); synchronises when read. */
 int pt_set_timing(pt_ctx *ctx, int32_t enable);
 int pt_last_trace_ms(pt_ctx *ctx, float *ms, int32_t *launches);
+
+/* ---- Multi-GPU ----------------------------------------------
+ * The reference has ONE `traces` (src/Lib.hs:53-56), read by app/Write.hs:24-28
+ * and app/Web.hs:42-65; these entry points keep it one however many GPUs render
+ * it.  The work shards by sample: the random stream is keyed by (pixel, global
+ * sample index, bounce), so any partition of a frame's sample indices over GPUs
+ * renders the same set of paths (equal up to fp32 summation order), and ONE
+ * RCCL all-reduce (sum) of the fp32 canvases over xGMI combines them.  No
+ * counterpart in the reference (it is single-threaded).  librccl is
+ * opened on first use; without it these calls return PT_ERR_UNSUPPORTED.
+ *
+ * One process, several devices: pt_create_multi is pt_create for a list of HIP
+ * device ordinals (params->device is ignored).  The context it returns is used
+ * exactly like any other: pt_scene_upload and pt_scene_specialise apply to every
+ * device; pt_trace(ctx, k) splits the call's k sample indices into contiguous
+ * blocks, one per device (k calls of 1 thus take turns on the first device --
+ * shard frames of many samples, not single ones); the first read after it
+ * (pt_read_sum*, pt_read_rgb8, pt_rgb8_device, pt_canvas_device_ptr) performs
+ * the all-reduce (ncclAllReduce per device, fp32 sum of H*W*3 values, out of
+ * place, so each device's canvas stays its partial sum and the render can go
+ * on) and returns the total from the first device; pt_segments sums the
+ * devices' counters.  A device may be listed up to 8 times (its members are
+ * then added by a kernel before the collective); pt_set_stream and
+ * pt_rgb8_device_on do not apply (PT_ERR_UNSUPPORTED). */
+int pt_create_multi(pt_ctx **out, const pt_params *params, const int32_t *devices, int32_t n_devices);
+
+/* One process per GPU: every rank creates an ordinary context with
+ * sample_offset = rank, sample_stride = n_ranks (or any other disjoint split).
+ * Rank 0 calls pt_comm_unique_id and hands the PT_COMM_ID_BYTES bytes to the
+ * others by its own means (MPI, a file, torch.distributed); every rank then
+ * calls pt_comm_init_rank (collective: it returns when all n_ranks have
+ * joined).  pt_allreduce_sum queues ncclAllReduce(sum) of the canvas on the
+ * context's stream into a second buffer; from then until the next pt_trace,
+ * pt_reset or pt_write_sum_f32 the reads of this context return the total of
+ * all ranks (in the MEAN modes pass the frame's whole sample count as
+ * samples_override).  pt_canvas_device_ptr keeps naming the rank's own partial
+ * sum.  Every rank must call pt_allreduce_sum the same number of times. */
+#define PT_COMM_ID_BYTES 128
+int pt_comm_unique_id(void *id);
+int pt_comm_init_rank(pt_ctx *ctx, const void *id, int32_t rank, int32_t n_ranks);
+int pt_allreduce_sum(pt_ctx *ctx);
+/* What a context's collective runs over: RCCL ranks, this context's rank, the
+ * devices driven from this process, and RCCL's version code (0: no
+ * communicator -- an ordinary single-GPU context).  Any pointer may be NULL. */
+int pt_comm_info(pt_ctx *ctx, int32_t *n_ranks, int32_t *rank, int32_t *n_local, int32_t *rccl_version);
 
 const char *pt_last_error(pt_ctx *ctx);
 

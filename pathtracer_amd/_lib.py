@@ -83,10 +83,17 @@ SIGNATURES = {
     "pt_dev_distance": (C.c_int, [_P, C.c_int32, C.POINTER(pt_object), _P, _P, _P]),
     "pt_dev_philox": (C.c_int, [_P, C.c_int32, _P, _P, C.c_uint32, _P]),
     "pt_scene_specialise": (C.c_int, [_P]),
+    "pt_jit_info": (C.c_int, [_P, C.c_char_p, C.c_size_t]),
     "pt_set_timing": (C.c_int, [_P, C.c_int32]),
     "pt_last_trace_ms": (C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_int32)]),
+    "pt_create_multi": (C.c_int, [C.POINTER(_P), C.POINTER(pt_params), C.POINTER(C.c_int32), C.c_int32]),
+    "pt_comm_unique_id": (C.c_int, [_P]),
+    "pt_comm_init_rank": (C.c_int, [_P, _P, C.c_int32, C.c_int32]),
+    "pt_allreduce_sum": (C.c_int, [_P]),
+    "pt_comm_info": (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "pt_last_error": (C.c_char_p, [_P]),
 }
+PT_COMM_ID_BYTES = 128
 
 
 def _share_torch_hip_runtime():

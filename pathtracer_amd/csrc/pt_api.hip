@@ -3,8 +3,7 @@
 // point runs HIP kernels on the context's device or fails.
 //
 // File:line citations are relative to the reference repository root.
-#include "../../include/pt.h"
-#include "pt_internal.hpp"
+#include "pt_ctx.hpp"
 #include "pt_bvh.hpp"
 
 #include <cmath>
@@ -18,45 +17,9 @@
 
 using namespace pt;
 
-struct pt_ctx {
-    pt_params p{};
-    hipStream_t own_stream = nullptr, stream = nullptr;
-    float *d_canvas = nullptr;
-    unsigned long long *d_segments = nullptr;   // ring of SEG_SLOTS counters, one per pt_reset epoch
-    int seg_slot = 0;
-    bool canvas_stale = false;                   // pt_reset defers the zeroing to the next pt_trace / read
-    float4 *d_geom = nullptr, *d_mat = nullptr;
-    double *d_prim = nullptr;
-    float4 *d_pix = nullptr;           // primary hits kept across launches (TraceArgs::pix); valid until the next scene upload
-    bool pix_valid = false;
-    float *d_partial = nullptr;        // sample-slice planes of a launch (pt_internal.hpp), allocated at the first large pt_trace
-    float4 *d_rect = nullptr;          // sides of Rectangle forms, 2 float4 per object; null without one
-    float4 *d_bvh_nodes = nullptr;               // spatial index over the finite forms (pt_bvh.hpp), or null
-    int32_t *d_bvh_prims = nullptr;
-    float4 *d_bvh_geom = nullptr;
-    int n_nodes = 0, n_unbounded = 0, bvh_depth = 0;
-    uint8_t *d_rgb = nullptr;
-    int n_obj = 0;
-    bool has_specular = false;
-    std::vector<float4> h_geom;   // host copy: small scenes ride in the kernel arguments
-    hipFunction_t scene_kernel = nullptr;   // trace_static_kernel compiled for this scene (pt_scene_specialise), or null
-    int64_t samples_done = 0;
-    bool timing = false;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    int last_launches = 0;
-    bool have_timing = false;
-    std::string err;
-};
+namespace pt {
 
-namespace {
-
-thread_local std::string g_err;   // for failures before a context exists
-
-constexpr int64_t MAX_GLOBAL_SAMPLES = (int64_t)1 << 26;   // sample index shares a Philox word with a 6-bit bounce
-constexpr int     MAX_BOUNCES = 64;
-constexpr int     MAX_OBJECTS = 65536;
-constexpr int     MAX_SAMPLES_PER_LAUNCH = 4096;
-constexpr int     SEG_SLOTS = 64;                 // pt_reset epochs before the ring is cleared
+static thread_local std::string g_err;   // for failures before a context exists
 
 int fail(pt_ctx *c, int status, const std::string &msg)
 {
@@ -64,14 +27,18 @@ int fail(pt_ctx *c, int status, const std::string &msg)
     return status;
 }
 
-#define PT_HIP(c, call)                                                                      \
-    do {                                                                                     \
-        hipError_t e_ = (call);                                                              \
-        if (e_ != hipSuccess)                                                                \
-            return fail((c), PT_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
-    } while (0)
+int check_ctx(pt_ctx *c)
+{
+    if (!c) return fail(nullptr, PT_ERR_INVALID, "null context");
+    if (c->group) return PT_OK;                       // a group head has no device of its own
+    hipError_t e = hipSetDevice(c->p.device);
+    if (e != hipSuccess) return fail(c, PT_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
+    return PT_OK;
+}
 
-size_t npix(const pt_ctx *c) { return (size_t)c->p.height * (size_t)c->p.width; }
+} // namespace pt
+
+namespace {
 
 // ---- host-side scene flattening (fp64, then rounded to fp32) ---------------
 // The per-object constants below are the wave-invariant part of
@@ -188,13 +155,6 @@ template <typename T> struct DevBuf {
     hipError_t down(T *h, size_t n) { return hipMemcpy(h, p, n * sizeof(T), hipMemcpyDeviceToHost); }
 };
 
-int check_ctx(pt_ctx *c)
-{
-    if (!c) return fail(nullptr, PT_ERR_INVALID, "null context");
-    hipError_t e = hipSetDevice(c->p.device);
-    if (e != hipSuccess) return fail(c, PT_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
-    return PT_OK;
-}
 
 } // namespace
 
@@ -262,6 +222,7 @@ int pt_create(pt_ctx **out, const pt_params *params)
         return bail("hipMemset", e);
     if ((e = hipEventCreate(&c->ev0)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipEventCreate(&c->ev1)) != hipSuccess) return bail("hipEventCreate", e);
+    if ((e = hipEventCreateWithFlags(&c->ev_sync, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return bail("hipStreamSynchronize", e);
     *out = c;
     return PT_OK;
@@ -270,6 +231,7 @@ int pt_create(pt_ctx **out, const pt_params *params)
 void pt_destroy(pt_ctx *c)
 {
     if (!c) return;
+    if (c->group) { group_destroy(c); delete c; return; }
     (void)hipSetDevice(c->p.device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->d_canvas) (void)hipFree(c->d_canvas);
@@ -284,6 +246,9 @@ void pt_destroy(pt_ctx *c)
     if (c->d_bvh_prims) (void)hipFree(c->d_bvh_prims);
     if (c->d_bvh_geom) (void)hipFree(c->d_bvh_geom);
     if (c->d_rgb) (void)hipFree(c->d_rgb);
+    if (c->d_hits) (void)hipFree(c->d_hits);
+    comm_destroy(c);
+    if (c->ev_sync) (void)hipEventDestroy(c->ev_sync);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -293,6 +258,7 @@ void pt_destroy(pt_ctx *c)
 int pt_scene_upload(pt_ctx *c, const pt_object *objs, int32_t n)
 {
     if (int s = check_ctx(c)) return s;
+    if (c->group) return group_scene_upload(c, objs, n);
     if (!objs) return fail(c, PT_ERR_INVALID, "pt_scene_upload: null objects");
     if (n < 1 || n > MAX_OBJECTS) return fail(c, PT_ERR_LIMIT, "pt_scene_upload: need 1 <= n <= 65536");
     for (int k = 0; k < n; ++k)
@@ -419,10 +385,23 @@ static void scene_args(const pt_ctx *c, TraceArgs &a)
 int pt_trace(pt_ctx *c, int32_t iters)
 {
     if (int s = check_ctx(c)) return s;
+    if (c->group) return group_trace(c, iters);
+    return trace_block(c, c->samples_done, iters);
+}
+
+} // extern "C"
+
+// `iters` more samples per pixel, the global samples offset + k*stride for k in [k_begin, k_begin + iters).
+// pt_trace continues the context's own count (k_begin = samples_done); a device group (pt_multi.hip) hands each
+// member a block of the call's range.
+int pt::trace_block(pt_ctx *c, int64_t k_begin, int32_t iters)
+{
+    if (int s = check_ctx(c)) return s;
     if (c->n_obj < 1) return fail(c, PT_ERR_NO_SCENE, "pt_trace: no scene uploaded");
-    if (iters < 0) return fail(c, PT_ERR_INVALID, "pt_trace: iters < 0");
+    if (iters < 0 || k_begin < 0) return fail(c, PT_ERR_INVALID, "pt_trace: iters < 0");
+    c->total_valid = false;
     const int64_t last_global =
-        (int64_t)c->p.sample_offset + (c->samples_done + iters) * (int64_t)c->p.sample_stride;
+        (int64_t)c->p.sample_offset + (k_begin + iters) * (int64_t)c->p.sample_stride;
     if (last_global >= MAX_GLOBAL_SAMPLES)       // the kernels shift (first index beyond the launch) << 6 in 32 bits
         return fail(c, PT_ERR_LIMIT, "pt_trace: global sample index would exceed 2^26");
 
@@ -449,7 +428,7 @@ int pt_trace(pt_ctx *c, int32_t iters)
         a.fresh = c->canvas_stale ? 1 : 0;           // the canvas is logically zero: do not read it
         scene_args(c, a);
         a.max_bounces = c->p.max_bounces; a.seed = c->p.seed;
-        a.sample_begin = (uint32_t)(c->p.sample_offset + c->samples_done * c->p.sample_stride);
+        a.sample_begin = (uint32_t)(c->p.sample_offset + k_begin * c->p.sample_stride);
         a.sample_stride = (uint32_t)c->p.sample_stride;
         a.n_samples = n;
         a.partial = c->d_partial;
@@ -461,6 +440,7 @@ int pt_trace(pt_ctx *c, int32_t iters)
         if (a.pix) c->pix_valid = true;              // later launches on this stream read what this one stored
         c->canvas_stale = false;
         c->samples_done += n;
+        k_begin += n;
         left -= n;
         ++launches;
     }
@@ -472,9 +452,12 @@ int pt_trace(pt_ctx *c, int32_t iters)
     return PT_OK;
 }
 
+extern "C" {
+
 int pt_scene_specialise(pt_ctx *c)
 {
     if (int s = check_ctx(c)) return s;
+    if (c->group) return group_scene_specialise(c);
     if (c->n_obj < 1) return fail(c, PT_ERR_NO_SCENE, "pt_scene_specialise: no scene uploaded");
     if (c->n_obj > MAX_STATIC_OBJECTS)
         return fail(c, PT_ERR_UNSUPPORTED, "pt_scene_specialise: only scenes of <= 8 objects have a kernel to specialise");
@@ -487,11 +470,22 @@ int pt_scene_specialise(pt_ctx *c)
     return PT_OK;
 }
 
+int pt_jit_info(pt_ctx *c, char *buf, size_t size)
+{
+    if (!c || !buf || size == 0) return fail(c, PT_ERR_INVALID, "pt_jit_info: bad argument");
+    pt_ctx *m = c->group ? group_first(c) : c;
+    const std::string info = m->scene_kernel ? jit_kernel_info(m->scene_kernel) : std::string();
+    std::snprintf(buf, size, "%s", info.c_str());
+    return PT_OK;
+}
+
+} // extern "C"
+
 // The canvas is zeroed lazily: the next pt_trace starts its sums from zero
 // without reading the buffer (saving a 25-MB fill and a 25-MB read per frame at
 // 1080p), and any read before that zeroes it first.  The segment counter moves
 // to the next slot of a pre-zeroed ring instead of being cleared.
-static int materialise_canvas(pt_ctx *c)
+int pt::materialise_canvas(pt_ctx *c)
 {
     if (c->canvas_stale) {
         PT_HIP(c, hipMemsetAsync(c->d_canvas, 0, npix(c) * 3 * sizeof(float), c->stream));
@@ -500,10 +494,41 @@ static int materialise_canvas(pt_ctx *c)
     return PT_OK;
 }
 
+// Conversion.repa3ToImage of `src` (a canvas of c's shape on c's device) into d_out, on `stream`
+int pt::rgb8_from(pt_ctx *c, const float *src, void *d_out, int32_t mode, int64_t samples, hipStream_t stream)
+{
+    if (!d_out) return fail(c, PT_ERR_INVALID, "pt_rgb8_device: null output");
+    if (mode < PT_RGB8_REFERENCE || mode > PT_RGB8_MEAN_GAMMA)
+        return fail(c, PT_ERR_INVALID, "pt_rgb8_device: unknown mode");
+    const double inv = samples > 0 ? 1.0 / (double)samples : 0.0;
+    PT_HIP(c, launch_rgb8(src, (uint8_t *)d_out, c->p.height, c->p.width, mode, inv, stream));
+    return PT_OK;
+}
+
+// What a read returns: the context's canvas, or -- for the head of a device group and for a rank context after
+// pt_allreduce_sum -- the sum over all GPUs (src/Lib.hs:53-56: there is ONE `traces`, however many GPUs render it).
+// `on` is the context whose stream orders the read.
+int pt::read_source(pt_ctx *c, pt_ctx **on, const float **src)
+{
+    if (c->group) {
+        if (int s = group_total(c, on)) return s;
+        *src = (*on)->d_total;
+        return check_ctx(*on);
+    }
+    if (int s = materialise_canvas(c)) return s;
+    *on = c;
+    *src = c->total_valid ? c->d_total : c->d_canvas;
+    return PT_OK;
+}
+
+extern "C" {
+
 int pt_reset(pt_ctx *c)
 {
     if (int s = check_ctx(c)) return s;
+    if (c->group) return group_reset(c);
     c->canvas_stale = true;
+    c->total_valid = false;
     if (++c->seg_slot == SEG_SLOTS) {
         PT_HIP(c, hipMemsetAsync(c->d_segments, 0, (size_t)SEG_SLOTS * SEG_EPOCH * sizeof(unsigned long long), c->stream));
         c->seg_slot = 0;
@@ -516,9 +541,10 @@ int pt_read_sum_f32(pt_ctx *c, float *out)
 {
     if (int s = check_ctx(c)) return s;
     if (!out) return fail(c, PT_ERR_INVALID, "pt_read_sum_f32: null output");
-    if (int s = materialise_canvas(c)) return s;
-    PT_HIP(c, hipMemcpyAsync(out, c->d_canvas, npix(c) * 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-    PT_HIP(c, hipStreamSynchronize(c->stream));
+    pt_ctx *on; const float *src;
+    if (int s = read_source(c, &on, &src)) return s;
+    PT_HIP(c, hipMemcpyAsync(out, src, npix(c) * 3 * sizeof(float), hipMemcpyDeviceToHost, on->stream));
+    PT_HIP(c, hipStreamSynchronize(on->stream));
     return PT_OK;
 }
 
@@ -532,32 +558,37 @@ int pt_read_sum(pt_ctx *c, double *out)
     return PT_OK;
 }
 
-static int rgb8_on(pt_ctx *c, void *d_out, int32_t mode, int64_t samples_override, hipStream_t stream)
+// samples to divide by in the MEAN modes: the caller's, else the context's (a group's: the whole group's) count
+} // extern "C"
+
+int64_t pt::mean_samples(pt_ctx *c, int64_t samples_override)
 {
-    if (int s = check_ctx(c)) return s;
-    if (!d_out) return fail(c, PT_ERR_INVALID, "pt_rgb8_device: null output");
-    if (mode < PT_RGB8_REFERENCE || mode > PT_RGB8_MEAN_GAMMA)
-        return fail(c, PT_ERR_INVALID, "pt_rgb8_device: unknown mode");
-    if (int s = materialise_canvas(c)) return s;
-    const int64_t ns = samples_override > 0 ? samples_override : c->samples_done;
-    const double inv = ns > 0 ? 1.0 / (double)ns : 0.0;
-    PT_HIP(c, launch_rgb8(c->d_canvas, (uint8_t *)d_out, c->p.height, c->p.width, mode, inv, stream));
-    return PT_OK;
+    if (samples_override > 0) return samples_override;
+    int64_t n = c->samples_done;
+    if (c->group) (void)group_samples_done(c, &n);
+    return n;
 }
+
+extern "C" {
 
 int pt_rgb8_device(pt_ctx *c, void *d_out, int32_t mode, int64_t samples_override)
 {
     if (int s = check_ctx(c)) return s;
-    return rgb8_on(c, d_out, mode, samples_override, c->stream);
+    pt_ctx *on; const float *src;
+    if (int s = read_source(c, &on, &src)) return s;
+    return rgb8_from(c, src, d_out, mode, mean_samples(c, samples_override), on->stream);
 }
 
 int pt_rgb8_device_on(pt_ctx *c, void *d_out, int32_t mode, int64_t samples_override, void *hip_stream)
 {
     if (int s = check_ctx(c)) return s;
     if (!hip_stream) return fail(c, PT_ERR_INVALID, "pt_rgb8_device_on: null stream");
+    if (c->group)               // a group's sum is formed on its members' own streams, which the caller cannot order against
+        return fail(c, PT_ERR_UNSUPPORTED, "pt_rgb8_device_on: not for a pt_create_multi context (use pt_rgb8_device)");
     if (c->canvas_stale)        // the lazy zero-fill would run on the context's stream, unordered with hip_stream
         return fail(c, PT_ERR_INVALID, "pt_rgb8_device_on: nothing traced since pt_reset");
-    return rgb8_on(c, d_out, mode, samples_override, (hipStream_t)hip_stream);
+    return rgb8_from(c, c->total_valid ? c->d_total : c->d_canvas, d_out, mode, mean_samples(c, samples_override),
+                     (hipStream_t)hip_stream);
 }
 
 int pt_read_rgb8(pt_ctx *c, uint8_t *out, int32_t mode)
@@ -565,44 +596,45 @@ int pt_read_rgb8(pt_ctx *c, uint8_t *out, int32_t mode)
     if (int s = check_ctx(c)) return s;
     if (!out) return fail(c, PT_ERR_INVALID, "pt_read_rgb8: null output");
     const size_t bytes = npix(c) * 3;
-    if (!c->d_rgb) PT_HIP(c, hipMalloc((void **)&c->d_rgb, bytes));
-    if (int s = pt_rgb8_device(c, c->d_rgb, mode, 0)) return s;
-    PT_HIP(c, hipMemcpyAsync(out, c->d_rgb, bytes, hipMemcpyDeviceToHost, c->stream));
-    PT_HIP(c, hipStreamSynchronize(c->stream));
+    pt_ctx *on; const float *src;
+    if (int s = read_source(c, &on, &src)) return s;
+    if (!on->d_rgb) PT_HIP(c, hipMalloc((void **)&on->d_rgb, bytes));
+    if (int s = rgb8_from(c, src, on->d_rgb, mode, mean_samples(c, 0), on->stream)) return s;
+    PT_HIP(c, hipMemcpyAsync(out, on->d_rgb, bytes, hipMemcpyDeviceToHost, on->stream));
+    PT_HIP(c, hipStreamSynchronize(on->stream));
     return PT_OK;
 }
 
 int pt_primary_hits(pt_ctx *c, int32_t *idx, double *t, double *normal)
 {
     if (int s = check_ctx(c)) return s;
+    if (c->group) {
+        pt_ctx *m = group_first(c);
+        const int s = pt_primary_hits(m, idx, t, normal);
+        if (s) c->err = m->err;
+        return s;
+    }
     if (c->n_obj < 1) return fail(c, PT_ERR_NO_SCENE, "pt_primary_hits: no scene uploaded");
+    // device staging for the three outputs (4 + 8 + 24 bytes per pixel), allocated once per context
     const size_t n = npix(c);
-    int32_t *d_idx = nullptr; double *d_t = nullptr, *d_n = nullptr;
-    int rc = PT_OK;
-    hipError_t e = hipSuccess;
-    do {
-        if (idx && (e = hipMalloc((void **)&d_idx, n * sizeof(int32_t))) != hipSuccess) break;
-        if (t && (e = hipMalloc((void **)&d_t, n * sizeof(double))) != hipSuccess) break;
-        if (normal && (e = hipMalloc((void **)&d_n, n * 3 * sizeof(double))) != hipSuccess) break;
-        TraceArgs a{};
-        scene_args(c, a);
-        if ((e = launch_primary(a, d_idx, d_t, d_n, c->stream)) != hipSuccess) break;
-        if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) break;
-        if (idx && (e = hipMemcpy(idx, d_idx, n * sizeof(int32_t), hipMemcpyDeviceToHost)) != hipSuccess) break;
-        if (t && (e = hipMemcpy(t, d_t, n * sizeof(double), hipMemcpyDeviceToHost)) != hipSuccess) break;
-        if (normal && (e = hipMemcpy(normal, d_n, n * 3 * sizeof(double), hipMemcpyDeviceToHost)) != hipSuccess) break;
-    } while (0);
-    if (e != hipSuccess) rc = fail(c, PT_ERR_HIP, std::string("pt_primary_hits: ") + hipGetErrorString(e));
-    if (d_idx) (void)hipFree(d_idx);
-    if (d_t) (void)hipFree(d_t);
-    if (d_n) (void)hipFree(d_n);
-    return rc;
+    if (!c->d_hits) PT_HIP(c, hipMalloc(&c->d_hits, n * 36));
+    double *d_t = (double *)c->d_hits, *d_n = d_t + n;
+    int32_t *d_idx = (int32_t *)(d_n + 3 * n);
+    TraceArgs a{};
+    scene_args(c, a);
+    PT_HIP(c, launch_primary(a, idx ? d_idx : nullptr, t ? d_t : nullptr, normal ? d_n : nullptr, c->stream));
+    if (idx) PT_HIP(c, hipMemcpyAsync(idx, d_idx, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    if (t) PT_HIP(c, hipMemcpyAsync(t, d_t, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (normal) PT_HIP(c, hipMemcpyAsync(normal, d_n, n * 3 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    PT_HIP(c, hipStreamSynchronize(c->stream));
+    return PT_OK;
 }
 
 int pt_segments(pt_ctx *c, uint64_t *out)
 {
     if (int s = check_ctx(c)) return s;
     if (!out) return fail(c, PT_ERR_INVALID, "pt_segments: null output");
+    if (c->group) return group_segments(c, out);
     unsigned long long lanes[SEG_EPOCH];
     PT_HIP(c, hipMemcpyAsync(lanes, c->d_segments + (size_t)c->seg_slot * SEG_EPOCH, sizeof lanes, hipMemcpyDeviceToHost, c->stream));
     PT_HIP(c, hipStreamSynchronize(c->stream));
@@ -615,6 +647,7 @@ int pt_segments(pt_ctx *c, uint64_t *out)
 int pt_samples_done(pt_ctx *c, int64_t *out)
 {
     if (!c || !out) return fail(c, PT_ERR_INVALID, "pt_samples_done: null argument");
+    if (c->group) return group_samples_done(c, out);
     *out = c->samples_done;
     return PT_OK;
 }
@@ -623,8 +656,15 @@ int pt_canvas_device_ptr(pt_ctx *c, void **dptr, size_t *bytes)
 {
     if (!c || !dptr) return fail(c, PT_ERR_INVALID, "pt_canvas_device_ptr: null argument");
     if (int s = check_ctx(c)) return s;
-    if (int s = materialise_canvas(c)) return s;
-    *dptr = c->d_canvas;
+    if (c->group) {             // the group's sum, on the first device; formed and complete when this returns
+        pt_ctx *on; const float *src;
+        if (int s = read_source(c, &on, &src)) return s;
+        PT_HIP(c, hipStreamSynchronize(on->stream));
+        *dptr = (void *)src;
+    } else {
+        if (int s = materialise_canvas(c)) return s;
+        *dptr = c->d_canvas;
+    }
     if (bytes) *bytes = npix(c) * 3 * sizeof(float);
     return PT_OK;
 }
@@ -632,6 +672,7 @@ int pt_canvas_device_ptr(pt_ctx *c, void **dptr, size_t *bytes)
 int pt_set_stream(pt_ctx *c, void *hip_stream)
 {
     if (int s = check_ctx(c)) return s;
+    if (c->group) return fail(c, PT_ERR_UNSUPPORTED, "pt_set_stream: a pt_create_multi context launches on its members' own streams");
     PT_HIP(c, hipStreamSynchronize(c->stream));
     c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
     return PT_OK;
@@ -640,6 +681,7 @@ int pt_set_stream(pt_ctx *c, void *hip_stream)
 int pt_synchronize(pt_ctx *c)
 {
     if (int s = check_ctx(c)) return s;
+    if (c->group) return group_synchronize(c);
     PT_HIP(c, hipStreamSynchronize(c->stream));
     return PT_OK;
 }
@@ -648,9 +690,11 @@ int pt_write_sum_f32(pt_ctx *c, const float *in, int64_t samples_done)
 {
     if (int s = check_ctx(c)) return s;
     if (!in || samples_done < 0) return fail(c, PT_ERR_INVALID, "pt_write_sum_f32: bad argument");
+    if (c->group) return group_write_sum_f32(c, in, samples_done);
     PT_HIP(c, hipMemcpyAsync(c->d_canvas, in, npix(c) * 3 * sizeof(float), hipMemcpyHostToDevice, c->stream));
     PT_HIP(c, hipStreamSynchronize(c->stream));
     c->canvas_stale = false;
+    c->total_valid = false;
     c->samples_done = samples_done;
     return PT_OK;
 }
@@ -658,6 +702,7 @@ int pt_write_sum_f32(pt_ctx *c, const float *in, int64_t samples_done)
 // ---- device-function parity hooks -------------------------------------------
 int pt_dev_diffuse(pt_ctx *c, int32_t n, const float *normal, const float *u, float *out)
 {
+    if (c && c->group) c = group_first(c);
     if (int s = check_ctx(c)) return s;
     if (n < 1 || !normal || !u || !out) return fail(c, PT_ERR_INVALID, "pt_dev_diffuse: bad argument");
     std::vector<float4> mat((size_t)n * 4);
@@ -680,6 +725,7 @@ int pt_dev_diffuse(pt_ctx *c, int32_t n, const float *normal, const float *u, fl
 int pt_dev_specular(pt_ctx *c, int32_t n, const float *vector, const float *normal, const float *u,
                     float noise, float *out)
 {
+    if (c && c->group) c = group_first(c);
     if (int s = check_ctx(c)) return s;
     if (n < 1 || !vector || !normal || !u || !out) return fail(c, PT_ERR_INVALID, "pt_dev_specular: bad argument");
     std::vector<float> nh((size_t)n * 3);
@@ -702,6 +748,7 @@ int pt_dev_specular(pt_ctx *c, int32_t n, const float *vector, const float *norm
 int pt_dev_distance(pt_ctx *c, int32_t n, const pt_object *obj, const float *origin, const float *vector,
                     float *t_out)
 {
+    if (c && c->group) c = group_first(c);
     if (int s = check_ctx(c)) return s;
     if (n < 1 || !obj || !origin || !vector || !t_out) return fail(c, PT_ERR_INVALID, "pt_dev_distance: bad argument");
     if (obj->kind != PT_INFINITE_PLANE && obj->kind != PT_DISK && obj->kind != PT_SPHERE && obj->kind != PT_RECTANGLE)
@@ -720,6 +767,7 @@ int pt_dev_distance(pt_ctx *c, int32_t n, const pt_object *obj, const float *ori
 
 int pt_dev_philox(pt_ctx *c, int32_t n, const uint32_t *c0, const uint32_t *c1, uint32_t key, uint32_t *out)
 {
+    if (c && c->group) c = group_first(c);
     if (int s = check_ctx(c)) return s;
     if (n < 1 || !c0 || !c1 || !out) return fail(c, PT_ERR_INVALID, "pt_dev_philox: bad argument");
     DevBuf<uint32_t> d0, d1, dout;
@@ -734,6 +782,7 @@ int pt_dev_philox(pt_ctx *c, int32_t n, const uint32_t *c0, const uint32_t *c1, 
 int pt_set_timing(pt_ctx *c, int32_t enable)
 {
     if (!c) return fail(nullptr, PT_ERR_INVALID, "pt_set_timing: null context");
+    if (c->group) return group_set_timing(c, enable);
     c->timing = enable != 0;
     c->have_timing = false;
     return PT_OK;
@@ -743,6 +792,7 @@ int pt_last_trace_ms(pt_ctx *c, float *ms, int32_t *launches)
 {
     if (int s = check_ctx(c)) return s;
     if (!ms) return fail(c, PT_ERR_INVALID, "pt_last_trace_ms: null output");
+    if (c->group) return group_last_trace_ms(c, ms, launches);
     if (!c->have_timing) return fail(c, PT_ERR_INVALID, "pt_last_trace_ms: no timed pt_trace yet");
     PT_HIP(c, hipEventSynchronize(c->ev1));
     PT_HIP(c, hipEventElapsedTime(ms, c->ev0, c->ev1));

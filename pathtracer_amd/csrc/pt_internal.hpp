@@ -89,6 +89,8 @@ namespace pt {
 // pt_jit.hip: trace_static_kernel<NS, spec> compiled by hiprtc with this geometry (n_obj * 3 float4, as uploaded)
 // as constants, loaded on `device`; cached per process.  Null and a reason in `err` on failure.
 hipFunction_t jit_static_kernel(int device, int n_obj, bool spec, const float4 *geom_host, std::string &err);
+// what compiled it: "hiprtc <major>.<minor> (<library file>), --offload-arch=..., __builtin_amdgcn_inverse_ballot_w64 available|missing"
+std::string jit_kernel_info(hipFunction_t fn);
 #endif
 
 } // namespace pt

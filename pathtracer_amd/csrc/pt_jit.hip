@@ -42,7 +42,9 @@ struct Rtc {
     int (*code_size)(rtc_program, size_t *) = nullptr;
     int (*code)(rtc_program, char *) = nullptr;
     int (*destroy)(rtc_program *) = nullptr;
+    int (*version)(int *, int *) = nullptr;
     bool ok = false;
+    std::string where;             // the file the entry points came from, and its version
 };
 
 Rtc &rtc()
@@ -63,12 +65,20 @@ Rtc &rtc()
         r.code_size = (decltype(r.code_size))sym("hiprtcGetCodeSize");
         r.code      = (decltype(r.code))sym("hiprtcGetCode");
         r.destroy   = (decltype(r.destroy))sym("hiprtcDestroyProgram");
+        r.version   = (decltype(r.version))sym("hiprtcVersion");
         r.ok = r.create && r.compile && r.log_size && r.log && r.code_size && r.code && r.destroy;
+        if (r.ok) {
+            int major = 0, minor = 0;
+            if (r.version) (void)r.version(&major, &minor);
+            Dl_info di{};
+            const bool known = dladdr((void *)r.compile, &di) != 0 && di.dli_fname;
+            r.where = "hiprtc " + std::to_string(major) + "." + std::to_string(minor) + " (" + (known ? di.dli_fname : "?") + ")";
+        }
     });
     return r;
 }
 
-struct Entry { hipModule_t mod = nullptr; hipFunction_t fn = nullptr; };
+struct Entry { hipModule_t mod = nullptr; hipFunction_t fn = nullptr; std::string info; };
 std::mutex g_mu;
 std::map<std::string, Entry> g_cache;      // (device, NS, SPEC, geometry bits) -> loaded kernel; lives until exit
 
@@ -107,7 +117,10 @@ hipFunction_t jit_static_kernel(int device, int n_obj, bool spec, const float4 *
         }
         src += "}";
     }
-    src += "}\n#include \"pt_static_kernel.hpp\"\n";
+    src += "}\n#include \"pt_static_kernel.hpp\"\n"
+           // which form lane_of()/pick() took in this compilation (pt_static_kernel.hpp), for pt_jit_info
+           "extern \"C\" __device__ __attribute__((used)) int pt_jit_has_inverse_ballot = "
+           "__has_builtin(__builtin_amdgcn_inverse_ballot_w64) ? 1 : 0;\n";
 
     const char *headers[] = {src_pt_static_kernel_hpp, src_pt_internal_hpp, src_pt_device_hpp};
     const char *names[] = {"pt_static_kernel.hpp", "pt_internal.hpp", "pt_device.hpp"};
@@ -144,8 +157,26 @@ hipFunction_t jit_static_kernel(int device, int n_obj, bool spec, const float4 *
         err = std::string("hipModuleGetFunction(") + sym + "): " + hipGetErrorString(he);
         return nullptr;
     }
+    int has = -1;
+    {
+        hipDeviceptr_t dp = nullptr; size_t nb = 0;
+        if (hipModuleGetGlobal(&dp, &nb, e.mod, "pt_jit_has_inverse_ballot") == hipSuccess && nb == sizeof(int)) {
+            if (hipMemcpy(&has, dp, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) has = -1;
+        }
+        (void)hipGetLastError();
+    }
+    e.info = r.where + ", " + arch + ", __builtin_amdgcn_inverse_ballot_w64 " +
+             (has == 1 ? "available" : has == 0 ? "missing (v_cndmask_b32 form)" : "unknown");
     g_cache.emplace(std::move(key), e);
     return e.fn;
+}
+
+std::string jit_kernel_info(hipFunction_t fn)
+{
+    std::lock_guard<std::mutex> lock(g_mu);
+    for (const auto &kv : g_cache)
+        if (kv.second.fn == fn) return kv.second.info;
+    return "";
 }
 
 } // namespace pt

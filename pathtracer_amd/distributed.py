@@ -98,11 +98,19 @@ class PipelinedFrames:
     rgb: two device uint8 buffers (rank 0 only, else None).
     """
 
-    def __init__(self, renderers, canvases, rgb, *, rank, spp_total, my_spp, mode, dist=None):
+    def __init__(self, renderers, canvases, rgb, *, rank, spp_total, my_spp, mode, dist=None, allreduce=None):
+        """allreduce(renderer, canvas): queues the frame's ONE collective after the trace on the current
+        stream and returns None (libpt's own ncclAllReduce, Renderer.allreduce_sum: it runs on the context's
+        stream and the output kernel then reads the context's total) or a work handle to wait on
+        (torch.distributed with async_op=True, in place on the canvas).  `dist` alone = the torch form."""
         import torch
         self.torch = torch
         self.r, self.cv, self.rgb = renderers, canvases, rgb
         self.rank, self.spp_total, self.my_spp, self.mode, self.dist = rank, spp_total, my_spp, mode, dist
+        if allreduce is None and dist is not None:
+            def allreduce(_r, cv):
+                return dist.all_reduce(cv, op=dist.ReduceOp.SUM, async_op=True)
+        self.allreduce = allreduce
         if torch.cuda.current_stream().cuda_stream == 0:
             raise ValueError("PipelinedFrames needs an explicit torch stream as the current stream: libpt cannot "
                              "be pointed at the legacy null stream (pt_set_stream(NULL) = the context's own stream)")
@@ -126,8 +134,8 @@ class PipelinedFrames:
             r.reset()
             r.trace(self.my_spp)
             work = None
-            if self.dist is not None:                        # RCCL's stream is ordered after `main` at this call
-                work = self.dist.all_reduce(cv, op=self.dist.ReduceOp.SUM, async_op=True)
+            if self.allreduce is not None:                   # ordered after the trace on `main` (torch: RCCL's stream
+                work = self.allreduce(r, cv)                 # waits on `main` at this call)
             traced = torch.cuda.Event()
             traced.record(main)
         with torch.cuda.stream(self.side):

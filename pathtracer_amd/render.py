@@ -12,15 +12,22 @@ from .scene import Object, Params, objects as default_objects, to_c_array
 
 
 class Renderer:
-    """One pt_ctx: Params + an uploaded scene + the fp32 radiance-sum canvas in HBM."""
+    """One pt_ctx: Params + an uploaded scene + the fp32 radiance-sum canvas in HBM.
+    `devices=[...]` makes it a pt_create_multi context: the same interface over several GPUs of this process,
+    every pt_trace sharded by sample index and the reads all-reduced over RCCL inside libpt."""
 
     def __init__(self, params: Params, objs: Optional[Sequence[Object]] = None, *, seed: int = 0,
-                 device: int = 0, sample_offset: int = 0, sample_stride: int = 1, flags: int = 0):
+                 device: int = 0, sample_offset: int = 0, sample_stride: int = 1, flags: int = 0,
+                 devices: Optional[Sequence[int]] = None):
         self.params = params
         p = _lib.pt_params(params.height, params.width, float(params.cameraDepth), params.maxBounces,
                            seed, device, sample_offset, sample_stride, flags)
         self._ctx = C.c_void_p()
-        check(lib.pt_create(C.byref(self._ctx), C.byref(p)))
+        if devices is None:
+            check(lib.pt_create(C.byref(self._ctx), C.byref(p)))
+        else:
+            arr = (C.c_int32 * len(devices))(*devices)
+            check(lib.pt_create_multi(C.byref(self._ctx), C.byref(p), arr, len(devices)))
         self.shape = (params.height, params.width, 3)
         if objs is None:
             objs = default_objects
@@ -129,6 +136,29 @@ class Renderer:
         """pt_rgb8_device on a caller-named stream (the caller orders it)."""
         check(lib.pt_rgb8_device_on(self._ctx, C.c_void_p(d_out), mode, samples, C.c_void_p(hip_stream)), self._ctx)
 
+    # -- multi-GPU, one process per GPU (include/pt.h: pt_comm_*) -------------
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        """Rank 0's RCCL id, to be handed to every other rank (PT_COMM_ID_BYTES bytes)."""
+        buf = C.create_string_buffer(_lib.PT_COMM_ID_BYTES)
+        check(lib.pt_comm_unique_id(buf))
+        return buf.raw
+
+    def comm_init_rank(self, uid: bytes, rank: int, n_ranks: int):
+        if len(uid) != _lib.PT_COMM_ID_BYTES:
+            raise ValueError("comm_init_rank: the id is PT_COMM_ID_BYTES bytes")
+        check(lib.pt_comm_init_rank(self._ctx, C.c_char_p(uid), rank, n_ranks), self._ctx)
+
+    def allreduce_sum(self):
+        """One ncclAllReduce(sum) of the canvas over all ranks, queued on the context's stream; the reads
+        return the total until the next trace / reset."""
+        check(lib.pt_allreduce_sum(self._ctx), self._ctx)
+
+    def comm_info(self) -> dict:
+        a, b, c, d = (C.c_int32() for _ in range(4))
+        check(lib.pt_comm_info(self._ctx, C.byref(a), C.byref(b), C.byref(c), C.byref(d)), self._ctx)
+        return {"n_ranks": a.value, "rank": b.value, "n_local": c.value, "rccl_version": d.value}
+
     def specialise(self) -> bool:
         """pt_scene_specialise: compile the trace kernel for this scene (seconds; worth it for a scene that is
         traced for a while).  True if the scene kernel is now in use, False if the library reported that the
@@ -138,6 +168,12 @@ class Renderer:
             return False
         check(s, self._ctx)
         return True
+
+    def jit_info(self) -> str:
+        """Which hiprtc compiled the scene kernel in use ("" = the general kernel)."""
+        buf = C.create_string_buffer(512)
+        check(lib.pt_jit_info(self._ctx, buf, len(buf)), self._ctx)
+        return buf.value.decode(errors="replace")
 
     def last_error(self) -> str:
         return (lib.pt_last_error(self._ctx) or b"").decode(errors="replace")

@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(raw, name), f"libpt.so does not export {name}"
         assert name in _lib.SIGNATURES, f"pathtracer_amd._lib has no signature for {name}"
     assert set(_lib.SIGNATURES) == set(declared_functions())
-    assert raw.pt_abi_version() == 2
+    assert raw.pt_abi_version() == 3
 
 
 def test_struct_layouts_match_the_header():
@@ -70,6 +70,15 @@ def test_argument_validation_needs_no_gpu():
     assert _lib.lib.pt_trace(None, 1) == _lib.PT_ERR_INVALID
     assert b"null" in _lib.lib.pt_last_error(None)
     _lib.lib.pt_destroy(None)                                   # no-op, must not crash
+    # multi-GPU entry points: argument checks come before any device or RCCL call
+    ok = _lib.pt_params(8, 8, 500.0, 4, 0, 0, 0, 1, 0)
+    devs = (C.c_int32 * 1)(0)
+    assert _lib.lib.pt_create_multi(C.byref(ctx), C.byref(ok), devs, 0) == _lib.PT_ERR_LIMIT
+    assert _lib.lib.pt_create_multi(C.byref(ctx), C.byref(ok), devs, 65) == _lib.PT_ERR_LIMIT
+    assert _lib.lib.pt_create_multi(C.byref(ctx), C.byref(ok), None, 1) == _lib.PT_ERR_INVALID
+    assert _lib.lib.pt_comm_unique_id(None) == _lib.PT_ERR_INVALID
+    assert _lib.lib.pt_allreduce_sum(None) == _lib.PT_ERR_INVALID
+    assert _lib.lib.pt_comm_init_rank(None, None, 0, 1) == _lib.PT_ERR_INVALID
 
 
 def test_product_never_touches_the_oracle():

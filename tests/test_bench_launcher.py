@@ -1,0 +1,50 @@
+"""bench.py --gpus N typed as is (no torch.distributed.run): the parent starts
+the N rank processes itself, before it imports torch or touches a GPU, and
+relays rank 0's single JSON line.  Checked here without a GPU: the rank
+environments, and a dry run in which the ranks only rendezvous over gloo."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def test_rank_environments():
+    import bench
+    envs = bench.rank_environments(4, 29555, base={"PATH": "/bin", "WORLD_SIZE": "stale"})
+    assert len(envs) == 4
+    for r, e in enumerate(envs):
+        assert e["RANK"] == str(r) and e["LOCAL_RANK"] == str(r)
+        assert e["WORLD_SIZE"] == "4" and e["LOCAL_WORLD_SIZE"] == "4"
+        assert e["MASTER_ADDR"] == "127.0.0.1" and e["MASTER_PORT"] == "29555"
+        assert e["PATH"] == "/bin"
+
+
+def _run(n):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["PT_BENCH_DRY_RUN"] = "1"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "1"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout                     # stdout carries exactly one line, the JSON
+    return json.loads(lines[0])
+
+
+def test_self_launch_starts_n_ranks_and_relays_one_json_line():
+    out = _run(3)
+    assert out == {"dry_run": True, "n_gpus": 3, "rank_sum": 1 + 2 + 3, "local_rank_sum": 1 + 2 + 3}
+
+
+def test_self_launch_reports_a_dead_rank():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    # no dry run and no GPU: every rank fails at "bench.py needs a GPU" (or on the box: this test is CPU-only)
+    if os.path.exists("/dev/kfd"):
+        import pytest
+        pytest.skip("needs a machine without a GPU")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0
+    assert p.stdout.strip() == ""
