@@ -36,7 +36,26 @@ def image(H, W, depth, bounces, spp, rng, seed, name):
                         camera_depth=depth, bounces=bounces, spp=spp, rng=rng, seed=seed)
 
 
+# Three 128x128 windows of the bench frame (1920x1080, depth 8) on the reference's own StdGen stream at 2048
+# samples per pixel, for the per-pixel statistical test at the bench resolution: the centre, a
+# corner, and a window over the analytic tie column j = W/2 - 100.
+CROPS = {"centre": (1920 // 2 - 64, 1080 // 2 - 64), "corner": (0, 0), "tie": (300, 1080 // 2 - 100 - 64)}
+
+
+def crops(H, W, depth, bounces, spp, name, threads=8):
+    out = {}
+    for key, (i0, j0) in CROPS.items():
+        px = O.crop_pixels(W, i0, j0)
+        s, sq, segs = O.trace_pixels_stdgen(O.params(H, W, depth, bounces, O.STDGEN), O.default_scene(), px, spp, threads)
+        out[key + "_sum"] = s.reshape(128, 128, 3)
+        out[key + "_sumsq"] = sq.reshape(128, 128, 3)
+        out[key + "_origin"] = np.array([i0, j0])
+        out[key + "_segments"] = segs
+    np.savez_compressed(os.path.join(HERE, name), H=H, W=W, camera_depth=depth, bounces=bounces, spp=spp, **out)
+
+
 if __name__ == "__main__":
+    crops(1920, 1080, 500.0, 8, 2048, "crops_stdgen_1920x1080_d8_2048spp.npz")
     primary(64, 64, 500.0, "primary_default_64x64.npz")
     primary(200, 200, 500.0, "primary_default_200x200.npz")
     # BASELINE config 1: default scene, 200x200, 16 spp, depth 4, the reference's own StdGen stream

@@ -144,6 +144,32 @@ def trace_pixels(p, objs, pixels, iters, s_begin=0, stride=1, threads=8):
     return out, segs.value
 
 
+def trace_pixels_stdgen(p, objs, pixels, iters, threads=8):
+    """The reference's own StdGen stream for the listed pixels (i*W + j) only: each keeps the generator that
+    startingGens gives it (src/Lib.hs:34-39: `randoms (mkStdGen 0)` in row-major pixel order) and threads it
+    through `iters` applications of traceCanvas (src/Lib.hs:58-65), so the sums equal the full-frame Tracer's at
+    those pixels.  -> (sum, sumsq, segments), (len(pixels), 3) each."""
+    assert p.rng == STDGEN
+    pixels = np.ascontiguousarray(pixels, np.int32)
+    every = (StdGen * (p.height * p.width))()
+    L.o_starting_gens(C.byref(p), every)
+    gens = (StdGen * len(pixels))()
+    for q, px in enumerate(pixels):
+        gens[q] = every[int(px)]
+    out = np.zeros((len(pixels), 3), np.float64)
+    sq = np.zeros((len(pixels), 3), np.float64)
+    segs = C.c_uint64(0)
+    L.o_trace_pixels(C.byref(p), objs, len(objs), pixels.ctypes.data, len(pixels), gens, 0, iters, 1,
+                     out.ctypes.data, sq.ctypes.data, C.byref(segs), threads)
+    return out, sq, segs.value
+
+
+def crop_pixels(W, i0, j0, size=128):
+    """Pixel indices i*W + j of the size x size window whose top-left pixel is (i0, j0), row-major."""
+    ii, jj = np.meshgrid(np.arange(i0, i0 + size), np.arange(j0, j0 + size), indexing="ij")
+    return (ii * W + jj).reshape(-1).astype(np.int32)
+
+
 def repa3_to_image(p, canvas):
     canvas = np.ascontiguousarray(canvas, np.float64)
     out = np.empty((p.width, p.height, 3), np.uint8)

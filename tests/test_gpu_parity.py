@@ -112,7 +112,7 @@ def test_dev_distance_plane_and_disk(pa, small):
         o64, v64 = org.astype(np.float64), vec.astype(np.float64)
         num, den = (pt - o64) @ nr, v64 @ nh
         cond = (np.abs(pt @ nr) + np.abs(o64 * nr).sum(1)) / np.abs(num) + np.abs(v64 * nh).sum(1) / np.abs(den)
-        bad = 0
+        bad = relaxed = hits = 0
         for k in range(n):
             d = O.C.c_double()
             ok = O.L.o_distance_from(O.vec(org[k]), O.vec(vec[k]), arr, O.C.byref(d))
@@ -121,10 +121,18 @@ def test_dev_distance_plane_and_disk(pa, small):
                 bad += 1
                 continue
             if ok:
-                # 1e-5 relative where the quotient is well conditioned, eps*cond beyond
-                tol = max(1e-5, 4 * 6e-8 * cond[k]) * abs(d.value) + 1e-6
-                assert abs(dev[k] - d.value) <= tol, (obj.name, k, dev[k], d.value, cond[k])
+                # north_star's bar: 1e-5 relative.  It holds wherever the fp32 quotient is well conditioned; a ray
+                # whose two dot products cancel (cond large) is allowed eps*cond instead, and such rays are COUNTED
+                hits += 1
+                err = abs(dev[k] - d.value)
+                if err > 1e-5 * abs(d.value) + 1e-6:
+                    relaxed += 1
+                    assert 4 * 6e-8 * cond[k] > 1e-5, (obj.name, k, dev[k], d.value, cond[k])   # only ill-conditioned rays
+                    assert err <= 4 * 6e-8 * cond[k] * abs(d.value) + 1e-6, (obj.name, k, dev[k], d.value, cond[k])
+        print(f"{obj.name}: {hits} hits, {relaxed} beyond 1e-5 relative (all with cond > 42), "
+              f"{bad} guard-boundary disagreements of {n} rays")
         assert bad <= n * 2e-3, (obj.name, bad)
+        assert relaxed <= hits * 5e-3, (obj.name, relaxed, hits)          # measured: <= 0.2 % of the hits
 
 
 def test_dev_diffuse(small):

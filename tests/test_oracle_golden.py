@@ -109,3 +109,34 @@ def test_repa3_to_image_layout():
     flat = img.reshape(-1)
     assert flat[(1 * H + 4) * 3 + 2] == 255 and flat[(2 * H + 0) * 3 + 0] == 128
     assert flat.sum() == 255 + 128
+
+
+def test_crop_fixture_is_what_the_oracle_computes():
+    """tests/golden/crops_stdgen_*.npz (the per-pixel statistical test's reference side, make_golden.py): a
+    seeded subset of each window recomputed here equals the committed sums exactly -- the pixel-subset tracer
+    threads each pixel's own StdGen (src/Lib.hs:34-39, :58-65), so a subset is bit-identical to the whole."""
+    g = np.load(os.path.join(G, "crops_stdgen_1920x1080_d8_2048spp.npz"))
+    H, W, spp = int(g["H"]), int(g["W"]), int(g["spp"])
+    assert (H, W, spp, int(g["bounces"])) == (1920, 1080, 2048, 8)
+    rng = np.random.default_rng(3)
+    for key in ("centre", "corner", "tie"):
+        i0, j0 = (int(x) for x in g[key + "_origin"])
+        pick = rng.choice(128 * 128, 24, replace=False)
+        px = O.crop_pixels(W, i0, j0)[pick]
+        s, sq, _ = O.trace_pixels_stdgen(O.params(H, W, 500.0, 8, O.STDGEN), O.default_scene(), px, spp, threads=4)
+        assert np.array_equal(s, g[key + "_sum"].reshape(-1, 3)[pick])
+        assert np.array_equal(sq, g[key + "_sumsq"].reshape(-1, 3)[pick])
+    # the window over the tie column really contains it (SURVEY.md 7: j = W/2 - 100)
+    i0, j0 = (int(x) for x in g["tie_origin"])
+    assert j0 <= W // 2 - 100 < j0 + 128
+
+
+def test_pixel_subset_stdgen_equals_the_full_frame_tracer():
+    H, W, B, spp = 40, 56, 6, 9
+    p = O.params(H, W, 500.0, B, O.STDGEN)
+    full = O.Tracer(p, O.default_scene(), threads=2)
+    full.trace(spp)
+    px = np.array([0, 5, W - 1, 17 * W + 3, H * W - 1], np.int32)
+    s, sq, _ = O.trace_pixels_stdgen(p, O.default_scene(), px, spp, threads=2)
+    assert np.array_equal(s, full.sum.reshape(-1, 3)[px])
+    assert np.array_equal(sq, full.sumsq.reshape(-1, 3)[px])
