@@ -167,6 +167,20 @@ int pt_read_sum_f32(pt_ctx *ctx, float *out);
 enum { PT_RGB8_REFERENCE = 0, PT_RGB8_MEAN_CLAMP = 1, PT_RGB8_MEAN_GAMMA = 2 };
 int pt_read_rgb8(pt_ctx *ctx, uint8_t *out, int32_t mode);
 
+/* pt_read_rgb8 for callers that cannot allocate.  No counterpart in the
+ * reference; it is for hosts that may not call hipMalloc where they read a frame:
+ * a tight serving loop (one pt_trace(1) + one read per client message, the
+ * pull-next-frame contract of app/Web.hs:42-65), code under HIP graph capture,
+ * harnesses that forbid allocation.  pt_read_rgb8 stages the quantised image in a
+ * device buffer it allocates on first use; this variant stages it in a static
+ * device array of 8 MiB that every GPU the library runs on holds until the
+ * process ends, and calls no hipMalloc / hipFree or allocating library routine.
+ * Same output, byte for byte.  Images above 8,388,608 bytes (H*W*3; 1920x1080
+ * fits) are refused with PT_ERR_LIMIT.  All contexts on one GPU share that GPU's
+ * array: calls that overlap in time on one GPU (two contexts, two threads) race
+ * -- serialise them. */
+int pt_read_rgb8_noalloc(pt_ctx *ctx, uint8_t *out, int32_t mode);
+
 /* Parity hook for rayFromCamToPixel + closestObjectTo on the primary ray
  * (src/Lib.hs:41-51, :81-98), evaluated in fp64 on the device: idx[i*W+j] is
  * the struck object or -1; t its ray parameter; normal[3] the struck form's

@@ -69,6 +69,7 @@ SIGNATURES = {
     "pt_read_sum": (C.c_int, [_P, _P]),
     "pt_read_sum_f32": (C.c_int, [_P, _P]),
     "pt_read_rgb8": (C.c_int, [_P, _P, C.c_int32]),
+    "pt_read_rgb8_noalloc": (C.c_int, [_P, _P, C.c_int32]),
     "pt_primary_hits": (C.c_int, [_P, _P, _P, _P]),
     "pt_segments": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
     "pt_samples_done": (C.c_int, [_P, C.POINTER(C.c_int64)]),

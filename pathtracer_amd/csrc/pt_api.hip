@@ -210,6 +210,7 @@ int pt_create(pt_ctx **out, const pt_params *params)
         return fail(nullptr, PT_ERR_HIP, m);
     };
     if ((e = hipSetDevice(p.device)) != hipSuccess) return bail("hipSetDevice", e);
+    if (scratch_init(nullptr, p.device) != PT_OK) { pt_destroy(c); return PT_ERR_HIP; }   // pt_noalloc.hip: the static scratch's address on this device
     if ((e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess)
         return bail("hipStreamCreate", e);
     c->stream = c->own_stream;

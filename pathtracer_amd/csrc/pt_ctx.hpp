@@ -76,6 +76,7 @@ int materialise_canvas(pt_ctx *c);
 int rgb8_from(pt_ctx *c, const float *src, void *d_out, int32_t mode, int64_t samples, hipStream_t stream);
 int read_source(pt_ctx *c, pt_ctx **on, const float **src);   // what a read returns (canvas or all-reduced total) and on whose stream
 int64_t mean_samples(pt_ctx *c, int64_t samples_override);
+int scratch_init(pt_ctx *c, int device);                       // pt_noalloc.hip
 
 // pt_multi.hip: what the C ABI entry points do for the head of a device group
 int  group_scene_upload(pt_ctx *head, const pt_object *objs, int32_t n);

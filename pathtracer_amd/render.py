@@ -99,6 +99,12 @@ class Renderer:
         check(lib.pt_read_rgb8(self._ctx, out.ctypes.data_as(C.c_void_p), mode), self._ctx)
         return out
 
+    def read_rgb8_noalloc(self, mode: int = _lib.PT_RGB8_REFERENCE) -> np.ndarray:
+        """read_rgb8 through the entry point that allocates nothing on the device (pt_read_rgb8_noalloc)."""
+        out = np.empty((self.params.width, self.params.height, 3), dtype=np.uint8)
+        check(lib.pt_read_rgb8_noalloc(self._ctx, out.ctypes.data_as(C.c_void_p), mode), self._ctx)
+        return out
+
     def primary_hits(self):
         H, W = self.params.height, self.params.width
         idx = np.empty((H, W), dtype=np.int32)
