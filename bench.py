@@ -209,10 +209,10 @@ def main():
     else:
         kind, count = ("disks", args.scene[5:]) if args.scene.startswith("disks") else ("spheres", args.scene[7:])
         n_obj = int(count)
-        gen = pa.random_disk_scene if kind == "disks" else pa.random_sphere_scene
-        scene = gen(n_obj, 1 if n_obj <= 1000 else 2)
-        scene_name = (f"synthetic {n_obj}-object random-{kind[:-1]} scene (SURVEY.md 8d generator, seed "
-                      f"{1 if n_obj <= 1000 else 2}" + ("; spheres are an extension without reference parity" if kind == "spheres" else "") + ")")
+        gen_seed = 1 if n_obj <= 1000 else 2
+        scene = pa.synthetic_scene(n_obj, gen_seed, kind)      # libpt's SplitMix64 generator (pt_synthetic_scene)
+        scene_name = (f"synthetic {n_obj}-object random-{kind[:-1]} scene (SURVEY.md 8d generator pt_synthetic_scene, "
+                      f"SplitMix64 seed {gen_seed}" + ("; spheres are an extension without reference parity" if kind == "spheres" else "") + ")")
     # An explicit stream: libpt cannot be pointed at the legacy null stream, and
     # the all-reduce must be ordered after the trace kernel on the SAME stream.
     stream = torch.cuda.Stream()

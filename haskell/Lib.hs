@@ -16,10 +16,11 @@ module Lib
   , traces
   ) where
 
-import           Data.Array.Repa        ((:.) (..), Array, D, DIM3, U, Z (..))
+import           Control.Concurrent.MVar (MVar, modifyMVar, newMVar)
+import           Control.Monad          (when)
+import           Data.Array.Repa        ((:.) (..), Array, D, DIM3, Z (..))
 import qualified Data.Array.Repa        as R
 import qualified Data.Vector            as V
-import qualified Data.Vector.Storable   as VS
 import           Data.Int               (Int32, Int64)
 import           Data.Word              (Word32)
 import           Foreign
@@ -72,6 +73,8 @@ instance Storable PtObject where
 foreign import ccall safe "pt_create"       c_pt_create       :: Ptr (Ptr PtCtx) -> Ptr PtParams -> IO CInt
 foreign import ccall safe "pt_scene_upload" c_pt_scene_upload :: Ptr PtCtx -> Ptr PtObject -> Int32 -> IO CInt
 foreign import ccall safe "pt_trace"        c_pt_trace        :: Ptr PtCtx -> Int32 -> IO CInt
+foreign import ccall safe "pt_reset"        c_pt_reset        :: Ptr PtCtx -> IO CInt
+foreign import ccall safe "pt_samples_done" c_pt_samples_done :: Ptr PtCtx -> Ptr Int64 -> IO CInt
 foreign import ccall safe "pt_scene_specialise" c_pt_scene_specialise :: Ptr PtCtx -> IO CInt
 foreign import ccall safe "pt_read_sum"     c_pt_read_sum     :: Ptr PtCtx -> Ptr Double -> IO CInt
 foreign import ccall safe "pt_last_error"   c_pt_last_error   :: Ptr PtCtx -> IO CString
@@ -84,6 +87,8 @@ check ctx st = do
   ioError (userError ("libpt status " ++ show st ++ ": " ++ msg))
 
 -- One context for the process, created on first use from Params.* and Object.objects.
+-- (Several GPUs: call pt_create_multi with a device list here instead of pt_create; nothing else changes --
+-- include/pt.h, "Multi-GPU".)
 {-# NOINLINE context #-}
 context :: ForeignPtr PtCtx
 context = unsafePerformIO $ alloca $ \pp -> with params $ \ppar -> do
@@ -99,22 +104,48 @@ context = unsafePerformIO $ alloca $ \pp -> with params $ \ppar -> do
     params = PtParams (fromIntegral Params.height) (fromIntegral Params.width) Params.cameraDepth
                       (fromIntegral Params.maxBounces) 0 0 0 1 0
 
--- Element k of `traces`: forces k-1 first (the list is built by lazy IO in
--- order), runs ONE more traceCanvas on the GPU and reads the running sum.
+canvasLen :: Int
+canvasLen = Params.height * Params.width * 3
+
+-- ONE host buffer for the whole process, and the index of the element of `traces` it holds (-1: none yet).
+-- `traces` is a CAF and app/Web.hs:43 walks it for as long as the server runs, so an element must not own
+-- memory: a buffer per element would grow by H*W*3 doubles per frame served (6 MB at 500x500), for ever.
+{-# NOINLINE slot #-}
+slot :: MVar (Int, ForeignPtr Double)
+slot = unsafePerformIO $ do
+  fp <- mallocForeignPtrArray canvasLen
+  newMVar (-1, fp)
+
+-- The buffer, holding element k.  Rendered on demand: forwards with the pt_trace calls not made yet (so the
+-- consecutive elements app/Web.hs pulls cost one traceCanvas each, and `traces !! numIters` of app/Write.hs:28
+-- costs ONE pt_trace numIters and ONE read), backwards -- an element older than the buffer's is asked for
+-- again -- with pt_reset and k fresh samples.  The random stream is keyed by (pixel, sample index, bounce),
+-- so element k holds the same numbers whenever it is rendered (up to fp32 summation order; bit for bit with
+-- PT_FLAG_NO_STEAL): the list stays a value.
+fetch :: Int -> IO (ForeignPtr Double)
+fetch k = modifyMVar slot $ \(have, fp) ->
+  if have == k
+    then return ((have, fp), fp)
+    else withForeignPtr context $ \ctx -> do
+      done <- alloca $ \pd -> do
+        c_pt_samples_done ctx pd >>= check ctx
+        fromIntegral <$> (peek pd :: IO Int64)
+      from <- if k < done then c_pt_reset ctx >>= check ctx >> return 0 else return done
+      when (k > from) $ c_pt_trace ctx (fromIntegral (k - from)) >>= check ctx
+      withForeignPtr fp $ \buf -> c_pt_read_sum ctx buf >>= check ctx
+      return ((k, fp), fp)
+
+-- Element k of `traces`: a delayed array that holds nothing but k.
 element :: Int -> Array D DIM3 Double
-element k = unsafePerformIO $ withForeignPtr context $ \ctx -> do
-  if k > 0 then c_pt_trace ctx 1 >>= check ctx else return ()
-  let n = Params.height * Params.width * 3
-  fp <- mallocForeignPtrArray n
-  withForeignPtr fp $ \buf -> c_pt_read_sum ctx buf >>= check ctx
-  let v = VS.unsafeFromForeignPtr0 fp n
-      sh = Z :. Params.height :. Params.width :. 3
-  return $ R.fromFunction sh (\ix -> v VS.! R.toIndex sh ix)
+element k = R.fromFunction sh $ \ix -> unsafePerformIO $ do
+  fp <- fetch k
+  withForeignPtr fp $ \buf -> peekElemOff buf (R.toIndex sh ix)
+  where
+    sh = Z :. Params.height :. Params.width :. 3
 
 -- traces :: [Array D DIM3 Double]  (src/Lib.hs:53-56): element k is the SUM of
--- k samples per pixel; element 0 is the black canvas.  `seqList` keeps the GPU
--- state in step with the list position.
+-- k samples per pixel; element 0 is the black canvas.
+-- (For the byte image, pt_read_rgb8 / pt_read_rgb8_noalloc with PT_RGB8_REFERENCE do repa3ToImage's work on
+-- the GPU -- Conversion.hs:22-28 -- and skip the per-index reads above; INTEGRATION.md.)
 traces :: [Array D DIM3 Double]
-traces = go 0
-  where
-    go k = let e = element k in e `seq` (e : go (k + 1))
+traces = map element [0 ..]

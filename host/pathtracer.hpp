@@ -88,6 +88,21 @@ inline std::vector<Object> objects()
     };
 }
 
+// The synthetic scenes of BASELINE.json configs[3]/[4], from libpt's generator so that every
+// host builds the same one: kind = PT_DISK (reference-expressible), PT_SPHERE or PT_RECTANGLE (extensions).
+inline std::vector<Object> syntheticScene(int n, uint64_t seed, int kind = PT_DISK)
+{
+    std::vector<pt_object> c((size_t)n);
+    if (pt_synthetic_scene(c.data(), n, seed, kind) != PT_OK) throw std::runtime_error("pt_synthetic_scene: bad argument");
+    std::vector<Object> out;
+    for (const pt_object &o : c) {
+        Form f{(Form::Kind)o.kind, {o.point[0], o.point[1], o.point[2]}, {o.normal[0], o.normal[1], o.normal[2]}, o.radius,
+               o.extent[0], o.extent[1]};
+        out.push_back(Object{{o.color[0], o.color[1], o.color[2]}, o.emittance, o.reflective != 0, f, ""});
+    }
+    return out;
+}
+
 struct PtError : std::runtime_error {
     int status;
     PtError(int s, const std::string &m) : std::runtime_error("libpt status " + std::to_string(s) + ": " + m), status(s) {}

@@ -6,6 +6,8 @@
 //
 // usage: write [--height H] [--width W] [--camera-depth D] [--iters N] [--bounces B]
 //              [--seed S] [--mode reference|mean|gamma] [--out image.png] [--device K]
+//              [--scene default|disksN|spheresN|rectanglesN]   N-object synthetic scene of BASELINE configs[3]/[4]
+//                                             (pt_synthetic_scene: seed 1 up to 1000 objects, else 2)
 //              [--gpus N | --devices a,b,c]   several GPUs of this process: the iterations are sharded by
 //                                             sample index and all-reduced over RCCL inside libpt (pt_create_multi)
 #include "pathtracer.hpp"
@@ -25,6 +27,7 @@ int main(int argc, char **argv)
     uint32_t seed = 0;
     int mode = PT_RGB8_REFERENCE, device = 0;
     std::vector<int32_t> devices;
+    std::string scene = "default";
     for (int i = 1; i < argc; ++i) {
         auto arg = [&](const char *name) { return !std::strcmp(argv[i], name) && i + 1 < argc; };
         if (arg("--height")) p.height = std::atoi(argv[++i]);
@@ -39,6 +42,7 @@ int main(int argc, char **argv)
             devices.clear();
             for (char *tok = std::strtok(argv[++i], ","); tok; tok = std::strtok(nullptr, ",")) devices.push_back(std::atoi(tok));
         }
+        else if (arg("--scene")) scene = argv[++i];
         else if (arg("--out")) out = argv[++i];
         else if (arg("--mode")) {
             const std::string m = argv[++i];
@@ -49,8 +53,17 @@ int main(int argc, char **argv)
         }
     }
     try {
-        std::unique_ptr<Lib::Traces> owner(devices.empty() ? new Lib::Traces(p, objects(), seed, device)
-                                                           : new Lib::Traces(p, objects(), devices, seed));
+        std::vector<Object> objs = objects();
+        if (scene != "default") {
+            const size_t digits = scene.find_first_of("0123456789");
+            const std::string kind = scene.substr(0, digits);
+            const int n = digits == std::string::npos ? 0 : std::atoi(scene.c_str() + digits);
+            const int code = kind == "disks" ? PT_DISK : kind == "spheres" ? PT_SPHERE : kind == "rectangles" ? PT_RECTANGLE : -1;
+            if (code < 0 || n < 1) { std::fprintf(stderr, "write: unknown --scene %s\n", scene.c_str()); return 2; }
+            objs = syntheticScene(n, n <= 1000 ? 1 : 2, code);
+        }
+        std::unique_ptr<Lib::Traces> owner(devices.empty() ? new Lib::Traces(p, objs, seed, device)
+                                                           : new Lib::Traces(p, objs, devices, seed));
         Lib::Traces &traces = *owner;
         const auto t0 = std::chrono::steady_clock::now();
         if ((int64_t)p.height * p.width * p.numIters >= (int64_t)1 << 26)

@@ -138,6 +138,21 @@ void pt_destroy(pt_ctx *ctx);
  * closestObjectTo breaks ties by position (src/Lib.hs:84).  1 <= n <= 65536. */
 int pt_scene_upload(pt_ctx *ctx, const pt_object *objs, int32_t n);
 
+/* The synthetic n-object scenes of BASELINE.json configs[3]/[4], generated as
+ * SURVEY.md 8(d) specifies so that every host builds the same scene from (n,
+ * seed): a SplitMix64 stream seeded with `seed`; object 0 the back plane z = 1500
+ * (normal (0,0,-1), white); objects 1..n-1 of form `finite_kind` (PT_DISK: the
+ * variant the reference's Form can express, src/Object.hs:51-56; PT_SPHERE,
+ * PT_RECTANGLE: the extensions) with, drawn in this order per object: centre
+ * uniform in x,y in [-400,400], z in [200,1200]; a uniformly random unit normal
+ * (rejection from the unit ball; zeroed for spheres); radius U(5,40) (a
+ * rectangle: height 2r, width 1.2r); colour U(0.2,1)^3; reflective with
+ * probability 1/2; emissive with probability 0.02, emittance U(1,5).  configs[3]
+ * is (1000, seed 1), configs[4] (10000, seed 2).  Host code: needs no GPU and no
+ * context.  No counterpart in the reference (its scene is the constant `objects`,
+ * src/Object.hs:147-148).  `out` holds n objects. */
+int pt_synthetic_scene(pt_object *out, int32_t n, uint64_t seed, int32_t finite_kind);
+
 /* `iters` applications of traceCanvas (src/Lib.hs:58-65): adds `iters` more
  * samples per pixel to the device canvas.  Sample indices continue from the
  * running count, so k calls of 1 render the same paths as one call of k (equal

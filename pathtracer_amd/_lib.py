@@ -64,6 +64,7 @@ SIGNATURES = {
     "pt_create": (C.c_int, [C.POINTER(_P), C.POINTER(pt_params)]),
     "pt_destroy": (None, [_P]),
     "pt_scene_upload": (C.c_int, [_P, C.POINTER(pt_object), C.c_int32]),
+    "pt_synthetic_scene": (C.c_int, [C.POINTER(pt_object), C.c_int32, C.c_uint64, C.c_int32]),
     "pt_trace": (C.c_int, [_P, C.c_int32]),
     "pt_reset": (C.c_int, [_P]),
     "pt_read_sum": (C.c_int, [_P, _P]),

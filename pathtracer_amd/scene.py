@@ -101,6 +101,34 @@ infPlane3 = Object((1, 1, 0.1), 0, False, InfinitePlane((20, -20, 100), (-1, 0, 
 objects = [infPlane, infPlane2, infPlane3, light]
 
 
+def from_c(o) -> Object:
+    """A pt_object back as an Object (the inverse of Object.to_c)."""
+    pt, nrm = tuple(o.point), tuple(o.normal)
+    if o.kind == _lib.PT_DISK:
+        form = Disk(pt, nrm, o.radius)
+    elif o.kind == _lib.PT_SPHERE:
+        form = Sphere(pt, o.radius)
+    elif o.kind == _lib.PT_RECTANGLE:
+        form = Rectangle(pt, nrm, o.extent[0], o.extent[1])
+    else:
+        form = InfinitePlane(pt, nrm)
+    return Object(tuple(o.color), o.emittance, bool(o.reflective), form)
+
+
+def synthetic_scene(n: int, seed: int, kind: str = "disks"):
+    """The synthetic n-object scene of BASELINE.json configs[3]/[4],
+    built by libpt's own generator (pt_synthetic_scene: SplitMix64) so that the
+    C++ and Haskell hosts get the same scene from (n, seed).  kind: "disks" (the
+    variant the reference can express), "spheres" or "rectangles" (extensions)."""
+    code = {"disks": _lib.PT_DISK, "spheres": _lib.PT_SPHERE, "rectangles": _lib.PT_RECTANGLE}[kind]
+    arr = (_lib.pt_object * n)()
+    _lib.check(_lib.lib.pt_synthetic_scene(arr, n, seed, code))
+    objs = [from_c(o) for o in arr]
+    for k, o in enumerate(objs):
+        o.name = "back plane" if k == 0 else f"{kind[:-1]} {k}"
+    return objs
+
+
 def random_sphere_scene(n: int, seed: int):
     """BASELINE.json configs[3] as written ("random-sphere scene"): the generator
     of random_disk_scene with every disk replaced by a sphere of the same centre
@@ -126,8 +154,9 @@ def random_rectangle_scene(n: int, seed: int):
 
 
 def random_disk_scene(n: int, seed: int):
-    """Synthetic n-object scene of SURVEY.md 8(d) (disk variant, expressible by
-    the reference's Form): object 0 is a back plane at z=1500, the rest are
+    """Random test scenes of the shape of SURVEY.md 8(d)'s (numpy's generator; the
+    parity tests' scenes -- the BENCHED synthetic scenes come from synthetic_scene,
+    i.e. libpt's SplitMix64 generator): object 0 is a back plane at z=1500, the rest are
     disks with random unit normals in x,y in [-400,400], z in [200,1200];
     radii U(5,40); colour U(0.2,1)^3; half reflective; 2% emissive U(1,5)."""
     import numpy as np

@@ -237,13 +237,13 @@ def _spot_check_scene(pa, H, W, objs, spp, bounces, cam, count, seed):
 
 
 def test_config4_thousand_disks_full_size(pa):
-    objs = pa.random_disk_scene(1000, 1)
+    objs = pa.synthetic_scene(1000, 1, "disks")      # BASELINE configs[3]'s scene (disk variant), libpt's generator
     segs = _spot_check_scene(pa, 3840, 2160, objs, 512, 8, 500.0, 160, 44)
     assert segs > 3840 * 2160 * 512                      # most primary rays hit something and bounce on
 
 
 def test_config5_ten_thousand_disks_full_image_reduced_spp(pa):
-    objs = pa.random_disk_scene(10000, 2)
+    objs = pa.synthetic_scene(10000, 2, "disks")
     _spot_check_scene(pa, 3840, 2160, objs, 256, 16, 500.0, 40, 45)
 
 
