@@ -19,6 +19,7 @@
 #include <dlfcn.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -52,9 +53,11 @@ Rtc &rtc()
     static Rtc r;
     static std::once_flag once;
     std::call_once(once, [] {
+        // PT_HIPRTC names the library file (experiments: one compiler against another in the same process)
+        if (const char *forced = getenv("PT_HIPRTC")) r.lib = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
         for (const char *name : {"libhiprtc.so", "libhiprtc.so.7", "/opt/rocm/lib/libhiprtc.so"}) {
-            r.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
             if (r.lib) break;
+            r.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
         }
         if (!r.lib) return;
         auto sym = [&](const char *n) { return dlsym(r.lib, n); };
@@ -96,6 +99,7 @@ hipFunction_t jit_static_kernel(int device, int n_obj, bool spec, const float4 *
     }
     std::string key((const char *)g.data(), g.size() * sizeof(float));
     key += (char)NS; key += (char)(spec ? 1 : 0); key += (char)device;
+    if (const char *e = getenv("PT_JIT_FLAGS")) key += e;
 
     std::lock_guard<std::mutex> lock(g_mu);
     auto it = g_cache.find(key);
@@ -129,8 +133,18 @@ hipFunction_t jit_static_kernel(int device, int n_obj, bool spec, const float4 *
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) { (void)hipGetLastError(); r.destroy(&prog); err = "hipGetDeviceProperties failed"; return nullptr; }
     std::string arch = std::string("--offload-arch=") + prop.gcnArchName;
-    const char *opts[] = {arch.c_str(), "-O3", "-std=c++17", "-fno-slp-vectorize"};     // the Makefile's code-generation flags
-    const int rc = r.compile(prog, 4, opts);
+    std::vector<const char *> opts = {arch.c_str(), "-O3", "-std=c++17", "-fno-slp-vectorize"};   // the Makefile's code-generation flags
+    // PT_JIT_FLAGS: further compiler options, separated by blanks (scheduling experiments; part of the cache key)
+    std::vector<std::string> extra;
+    if (const char *e = getenv("PT_JIT_FLAGS")) {
+        std::string cur;
+        for (const char *q = e;; ++q) {
+            if (*q == ' ' || *q == '\0') { if (!cur.empty()) extra.push_back(cur); cur.clear(); if (!*q) break; }
+            else cur += *q;
+        }
+    }
+    for (const std::string &x : extra) opts.push_back(x.c_str());
+    const int rc = r.compile(prog, (int)opts.size(), opts.data());
     if (rc != 0) {
         size_t n = 0;
         r.log_size(prog, &n);

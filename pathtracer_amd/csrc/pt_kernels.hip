@@ -943,12 +943,15 @@ static hipError_t launch_trace_ns(TraceArgs a, const float4 *geom_host, bool reu
             }
             const dim3 sgrid((npix + STATIC_BLOCK - 1) / STATIC_BLOCK, a.n_slices), sblock(STATIC_BLOCK);
             hipError_t e;
+            // PT_EXTRA_LDS=<bytes>: unused dynamic LDS per workgroup, to lower the waves per SIMD for an occupancy
+            // experiment (160 KB per CU: 10240 -> 4 waves per SIMD, 20480 -> 2)
+            static const unsigned extra_lds = getenv("PT_EXTRA_LDS") ? (unsigned)atoi(getenv("PT_EXTRA_LDS")) : 0u;
             if (scene_kernel) {                                // the same kernel compiled for this scene (pt_jit.hip)
                 void *params[] = {&a, &sg};
-                e = hipModuleLaunchKernel(scene_kernel, sgrid.x, sgrid.y, 1, STATIC_BLOCK, 1, 1, 0, s, params, nullptr);
+                e = hipModuleLaunchKernel(scene_kernel, sgrid.x, sgrid.y, 1, STATIC_BLOCK, 1, 1, extra_lds, s, params, nullptr);
             } else {
-                if (spec) hipLaunchKernelGGL((trace_static_kernel<NS, true>), sgrid, sblock, 0, s, a, sg);
-                else      hipLaunchKernelGGL((trace_static_kernel<NS, false>), sgrid, sblock, 0, s, a, sg);
+                if (spec) hipLaunchKernelGGL((trace_static_kernel<NS, true>), sgrid, sblock, extra_lds, s, a, sg);
+                else      hipLaunchKernelGGL((trace_static_kernel<NS, false>), sgrid, sblock, extra_lds, s, a, sg);
                 e = hipGetLastError();
             }
             if (e == hipSuccess && a.n_slices > 1) {
