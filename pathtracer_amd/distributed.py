@@ -118,6 +118,12 @@ class PipelinedFrames:
         # frame k+1's kernel fills the CUs that the tail of frame k's kernel leaves idle.
         self.mains = [torch.cuda.current_stream(), None]
         self.mains[1], self._spare = stream_on_another_queue(self.mains[0])
+        # The output stream has the DEFAULT priority, on purpose.  On a high-priority stream (hipStreamCreateWithPriority)
+        # this same loop can hang in drain(): reproduced in round 2 with and without a collective, depending only on
+        # which streams the process had created before (profiles/r02_priority_probe.txt).  The
+        # stream/event graph below has no cycle -- it drains with its three streams on three hardware queues and
+        # with all of them forced onto one (tests/test_gpu_pipeline.py) -- so the wait that never ends is inside the
+        # runtime's handling of waits between queues of different priority, which this loop therefore never creates.
         self.side = torch.cuda.Stream()
         for r, m in zip(renderers, self.mains):
             r.set_stream(m.cuda_stream)

@@ -46,6 +46,44 @@ def test_pipelined_frames_equal_inline_frames():
         assert np.array_equal(img, want)
 
 
+@pytest.mark.parametrize("sharing", ["side_on_trace_stream_1", "side_on_trace_stream_0", "one_stream_for_everything"])
+def test_pipeline_drains_when_its_streams_share_a_queue(sharing):
+    """HIP maps streams onto a few in-order hardware queues, and a wait between streams becomes a barrier packet that
+    blocks its whole queue; a loop whose waits formed a cycle through a shared queue would hang (round 1 saw a hang
+    with a high-priority output stream).  PipelinedFrames' graph -- trace stream b waits for the output
+    of frame k-2, the output stream waits for the trace (and collective) of frame k -- has no such cycle: forced
+    onto shared streams, the worst mapping there is, every frame still arrives and equals the in-line frame."""
+    import torch
+    import pathtracer_amd as pa
+    from pathtracer_amd.distributed import PipelinedFrames, canvas_tensor
+
+    H, W, SPP, B = 160, 96, 6, 6
+    P = pa.Params(H, W, 500.0, SPP, B)
+    with pa.Renderer(P, seed=3) as ref:
+        ref.trace(SPP)
+        want = ref.read_rgb8(pa.PT_RGB8_MEAN_CLAMP)
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        rs = [pa.Renderer(P, seed=3) for _ in range(2)]
+        for q in rs:                                      # libpt's own collective, world of 1, as bench.py ships it
+            q.comm_init_rank(pa.Renderer.comm_unique_id(), 0, 1)
+        cvs = [canvas_tensor(q, 0) for q in rs]
+        rgbs = [torch.zeros(H * W * 3, dtype=torch.uint8, device="cuda") for _ in rs]
+        pipe = PipelinedFrames(rs, cvs, rgbs, rank=0, spp_total=SPP, my_spp=SPP, mode=pa.PT_RGB8_MEAN_CLAMP,
+                               allreduce=lambda q, cv: q.allreduce_sum())
+        if sharing == "one_stream_for_everything":
+            pipe.mains[1] = pipe.mains[0]
+            rs[1].set_stream(pipe.mains[0].cuda_stream)
+        pipe.side = pipe.mains[0] if sharing != "side_on_trace_stream_1" else pipe.mains[1]
+        for _ in range(7):
+            pipe.step()
+        pipe.drain()
+        for g in rgbs:
+            assert np.array_equal(g.cpu().numpy().reshape(W, H, 3), want)
+        for q in rs:
+            q.close()
+
+
 def test_pipeline_refuses_the_null_stream():
     import torch
     import pathtracer_amd as pa
