@@ -42,6 +42,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP32_VALU_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (vector)"
+GATHER_PEAK_GBS = 8216.0           # fully divergent 16-byte gathers, measured: tools/ubench_gather.hip, profiles/r02_bvh_roofline.txt
 
 
 def flops_per_segment(objs):
@@ -383,9 +384,28 @@ def main():
                                  "157.3 TFLOP/s (= the fp32 MFMA peak)"},
         }
         if indexed:
-            out["roofline"].update(achieved=None, frac=None, traffic=None,
-                                   note="searched through the BVH: the linear-scan flop formula does not apply; "
-                                        "see value (Mrays/s) and DESIGN.md 3.4")
+            # trace_bvh_kernel is bound by its per-lane 16-byte gathers (one per index node visited, three per
+            # object record), served by the CU's address unit and L1/L2 -- not by HBM, VALU or MFMA.  Algorithmic
+            # bytes per launch = 16 B x the gathers the kernel counted (pt_bvh_counters); peak = the rate of fully
+            # divergent 16-byte gathers measured on MI355X by tools/ubench_gather.hip (profiles/r02_bvh_roofline.txt:
+            # 513.5 G gathers/s = 8,216 GB/s from an L1-resident table; 267-282 G/s = 4.3-4.5 TB/s once the table
+            # only fits L2 -- the kernel's hot top levels sit in between).
+            nodes, recs = r.bvh_counters()
+            gathers = (nodes + recs) / max(launches, 1)
+            ach = gathers * 16 / (kern_ms * 1e-3) / 1e9
+            out["roofline"] = {"bound": "l1-gather", "achieved": round(ach, 1), "peak": GATHER_PEAK_GBS, "unit": "GB/s",
+                               "frac": round(ach / GATHER_PEAK_GBS, 4), "traffic": None,
+                               "kernel": "trace_bvh_kernel", "kernel_ms": round(kern_ms, 4),
+                               "kernel_ms_mode": out["roofline"]["kernel_ms_mode"],
+                               "gathers_per_segment": round(gathers / max(segs_launch_rank0, 1), 2),
+                               "index_nodes_per_segment": round(nodes / max(launches, 1) / max(segs_launch_rank0, 1), 2),
+                               "object_record_gathers_per_segment": round(recs / max(launches, 1) / max(segs_launch_rank0, 1), 2),
+                               "segments_per_launch": int(segs_launch_rank0),
+                               "note": "divergent 16-byte per-lane gathers (index nodes and object records) bound this "
+                                       "kernel; algorithmic bytes = 16 B x gathers counted by the kernel "
+                                       "(pt_bvh_counters); peak = measured rate of such gathers from an L1-resident "
+                                       "table (tools/ubench_gather.hip, profiles/r02_bvh_roofline.txt); the linear-scan "
+                                       "flop formula of SURVEY 8d does not describe an indexed search"}
         if args.scene != "default":
             out["metric"] = "Mrays/s (samples x bounces)"
         if world == 1 and not args.no_cpu_baseline and args.scene == "default":

@@ -210,6 +210,15 @@ int pt_primary_hits(pt_ctx *ctx, int32_t *idx, double *t, double *normal);
 int pt_segments(pt_ctx *ctx, uint64_t *out);
 int pt_samples_done(pt_ctx *ctx, int64_t *out);
 
+/* Measurement hook for scenes searched through the spatial index (more than 8
+ * objects, default flags): since the last pt_reset, how many index nodes the
+ * per-lane walks visited (one 16-byte gather each) and how many 16-byte gathers
+ * they spent on object records (three per record) -- the traffic that bounds
+ * that kernel.  Zero for the other kernels; a pt_create_multi context reports its
+ * first device.  Any pointer may be NULL.  No counterpart in the reference,
+ * whose closestObjectTo is a linear scan (src/Lib.hs:81-98). */
+int pt_bvh_counters(pt_ctx *ctx, uint64_t *node_gathers, uint64_t *record_gathers);
+
 /* Device-side access for hosts that own GPU memory (torch, RCCL): the canvas
  * device pointer (H*W*3 floats) for an all-reduce, the stream the context
  * launches on, and a device-resident RGB8 image.  pt_set_stream takes a

@@ -645,6 +645,20 @@ int pt_segments(pt_ctx *c, uint64_t *out)
     return PT_OK;
 }
 
+int pt_bvh_counters(pt_ctx *c, uint64_t *node_visits, uint64_t *records)
+{
+    if (int s = check_ctx(c)) return s;
+    if (c->group) c = group_first(c);
+    unsigned long long lanes[SEG_EPOCH];
+    PT_HIP(c, hipMemcpyAsync(lanes, c->d_segments + (size_t)c->seg_slot * SEG_EPOCH, sizeof lanes, hipMemcpyDeviceToHost, c->stream));
+    PT_HIP(c, hipStreamSynchronize(c->stream));
+    unsigned long long v = 0, r = 0;
+    for (int l = 0; l < SEG_LANES; ++l) { v += lanes[l * SEG_LANE_STRIDE + 1]; r += lanes[l * SEG_LANE_STRIDE + 2]; }
+    if (node_visits) *node_visits = (uint64_t)v;
+    if (records) *records = (uint64_t)r;
+    return PT_OK;
+}
+
 int pt_samples_done(pt_ctx *c, int64_t *out)
 {
     if (!c || !out) return fail(c, PT_ERR_INVALID, "pt_samples_done: null argument");

@@ -683,6 +683,9 @@ __global__ __launch_bounds__(BVH_BLOCK) void trace_bvh_kernel(TraceArgs a)
     const int B = a.max_bounces;
 
     uint32_t segs = in_canvas ? 1u : 0u;                   // the fp64 primary search below (a lane runs < 2^32 searches per launch)
+    // what bounds this kernel: 16-byte per-lane gathers (one per node visited, three per object record).
+    // Counted per lane, summed per wave at the end, next to the segment counter (pt_bvh_counters, include/pt.h).
+    uint32_t n_nodes_visited = 0, n_records = 0;
     f3 acc = mk3(0.f, 0.f, 0.f);
     if (in_canvas && !a.fresh) acc = mk3(a.canvas[3 * (size_t)pc + 0], a.canvas[3 * (size_t)pc + 1], a.canvas[3 * (size_t)pc + 2]);
 
@@ -859,10 +862,14 @@ __global__ __launch_bounds__(BVH_BLOCK) void trace_bvh_kernel(TraceArgs a)
                     wsp += 1;
                     wn = right_first ? right : left;
                 }
+                n_nodes_visited += (uint32_t)steps;
                 if (code >= 0) {
                     const int first = code >> 3, cnt = (code & 7) + 1;
+                    n_records += 3u * (uint32_t)((cnt + 1) & ~1);     // 16-byte gathers: three per record slot (slots are fetched in pairs)
 #pragma unroll 1
                     for (int h = 0; h < BVH_LEAF_SLOTS; h += 2) {
+                        // (fetching a record's third vector only where its plane distance can still win saves 10 % of
+                        // the gathers and costs 4.5 % in time -- a second dependent round trip per pair; measured, dropped)
                         float4 r[2][3];
 #pragma unroll
                         for (int q = 0; q < 2; ++q) {
@@ -885,10 +892,19 @@ __global__ __launch_bounds__(BVH_BLOCK) void trace_bvh_kernel(TraceArgs a)
         a.canvas[3 * (size_t)pc + 1] = s_acc[tid * 3 + 1];
         a.canvas[3 * (size_t)pc + 2] = s_acc[tid * 3 + 2];
     }
-    unsigned long long wsegs = segs;
+    unsigned long long wsegs = segs, wnodes = n_nodes_visited, wrecs = n_records;
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) wsegs += __shfl_down(wsegs, off, 64);
-    if ((tid & 63) == 0 && wsegs) atomicAdd(seg_lane(a.segments), wsegs);
+    for (int off = 32; off > 0; off >>= 1) {
+        wsegs += __shfl_down(wsegs, off, 64);
+        wnodes += __shfl_down(wnodes, off, 64);
+        wrecs += __shfl_down(wrecs, off, 64);
+    }
+    if ((tid & 63) == 0 && wsegs) {
+        unsigned long long *line = seg_lane(a.segments);              // one 128-byte line: [0] segments, [1] nodes, [2] records
+        atomicAdd(line, wsegs);
+        atomicAdd(line + 1, wnodes);
+        atomicAdd(line + 2, wrecs);
+    }
 }
 
 

@@ -120,6 +120,13 @@ class Renderer:
         check(lib.pt_segments(self._ctx, C.byref(v)), self._ctx)
         return v.value
 
+    def bvh_counters(self):
+        """(16-byte gathers of index nodes, 16-byte gathers of object records) since the last reset, for scenes
+        searched through the spatial index."""
+        a, b = C.c_uint64(), C.c_uint64()
+        check(lib.pt_bvh_counters(self._ctx, C.byref(a), C.byref(b)), self._ctx)
+        return a.value, b.value
+
     @property
     def samples_done(self) -> int:
         v = C.c_int64()
