@@ -8,11 +8,13 @@
 // with the SAME arithmetic as the linear scan, and ties are broken by object
 // index as Data.Vector.minimumBy does, so the winner is the linear scan's winner.
 //
-// Layout: binary BVH in depth-first order, one 16-byte node per box.  A lane
-// walks it near child first (by the sign of the ray direction along the node's
-// split axis) with a short per-lane stack of far children in LDS; every node is
-// one 16-byte gather from L2.  Depth is bounded (BVH_MAX_DEPTH) so the stack
-// cannot overflow whatever the scene.
+// Layout: binary BVH in BREADTH-first order, one 16-byte node per box, the two
+// children of a node next to each other.  A lane walks it near child first (by
+// the sign of the ray direction along the node's split axis) with a short
+// per-lane stack of far children in LDS; every node is one 16-byte gather.  In
+// level order the first K nodes are the top of the tree -- the nodes every walk
+// visits -- which trace_bvh_kernel keeps in LDS.  Depth is bounded
+// (BVH_MAX_DEPTH) so the stack cannot overflow whatever the scene.
 #pragma once
 
 #include <algorithm>
@@ -29,7 +31,7 @@ namespace pt {
 // values rounded OUTWARD, plus one code word.
 //   h[0..2] = lo.xyz, h[3..5] = hi.xyz   (a coordinate beyond binary16's range becomes +-Inf: still conservative)
 //   code >= 0: leaf, first_prim << 3 | (count - 1)
-//   code <  0: inner node, -(c + 1) with c = right_child << 2 | split_axis; left child = this + 1
+//   code <  0: inner node, -(c + 1) with c = left_child << 2 | split_axis; right child = left child + 1
 struct BvhNode {
     uint16_t h[6];
     int32_t code;
@@ -101,7 +103,23 @@ public:
     {
         prim_base_ = prim_base;
         out_ = &out;
-        emit(0, (int)order_.size(), 0);
+        // level order: a queue of (range of order_, depth, node index); children are allocated in pairs
+        struct Item { int b, e, depth, me; };
+        std::vector<Item> queue;
+        out.nodes.push_back(BvhNode{});
+        queue.push_back(Item{0, (int)order_.size(), 0, 0});
+        for (size_t head = 0; head < queue.size(); ++head) {
+            const Item it = queue[head];
+            int mid = 0, axis = 0;
+            if (!emit(it.b, it.e, it.depth, it.me, mid, axis)) continue;       // a leaf
+            const int32_t first = (int32_t)out.nodes.size();
+            out.nodes.push_back(BvhNode{});
+            out.nodes.push_back(BvhNode{});
+            out.nodes[it.me].code = -(((first << 2) | axis) + 1);
+            queue.push_back(Item{it.b, mid, it.depth + 1, first});               // the low side of `axis` first
+            queue.push_back(Item{mid, it.e, it.depth + 1, first + 1});
+            if (it.depth + 1 > max_depth) max_depth = it.depth + 1;
+        }
         for (int32_t id : order_) out.prims.push_back(id);
     }
 
@@ -109,7 +127,6 @@ private:
     const std::vector<BvhBox> &boxes_;
     double pad_;
     std::vector<int32_t> order_;          // positions into boxes_ == object ids are looked up via ids
-    std::vector<int32_t> end_;
     Bvh *out_ = nullptr;
     int32_t prim_base_ = 0;
 
@@ -131,12 +148,10 @@ private:
     }
     double centroid(int i, int a) const { return 0.5 * (boxes_[order_[i]].lo[a] + boxes_[order_[i]].hi[a]); }
 
-    // emits the subtree over order_[b, e) in depth-first order
-    void emit(int b, int e, int depth)
+    // fills node `me` with the box of order_[b, e); a leaf if it holds few enough objects (-> false), else splits
+    // the range at `mid` along `axis` (-> true; the caller allocates the children)
+    bool emit(int b, int e, int depth, int me, int &mid, int &axis)
     {
-        const int me = (int)out_->nodes.size();
-        out_->nodes.push_back(BvhNode{});
-        end_.push_back(0);
         const BvhBox bb = bounds(b, e);
         BvhNode n;
         for (int a = 0; a < 3; ++a) {
@@ -148,8 +163,7 @@ private:
         if (cnt <= BVH_LEAF_MAX) {
             n.code = ((prim_base_ + b) << 3) | (cnt - 1);
             out_->nodes[me] = n;
-            end_[me] = (int32_t)out_->nodes.size();
-            return;
+            return false;
         }
         n.code = -1;
         out_->nodes[me] = n;
@@ -191,7 +205,7 @@ private:
             }
             if (best_axis == a) { split_min_ = cmin; split_scale_ = scale; }
         }
-        int mid, axis = best_axis;
+        axis = best_axis;
         if (best_axis >= 0) {
             const int a = best_axis; const double cmin = split_min_, scale = split_scale_; const int ks = best_split;
             auto it = std::partition(order_.begin() + b, order_.begin() + e, [&](int32_t id) {
@@ -211,12 +225,7 @@ private:
                 return boxes_[p].lo[a] + boxes_[p].hi[a] < boxes_[q].lo[a] + boxes_[q].hi[a];
             });
         }
-        emit(b, mid, depth + 1);                       // the low side of `axis` first
-        const int32_t right = (int32_t)out_->nodes.size();
-        emit(mid, e, depth + 1);
-        out_->nodes[me].code = -(((right << 2) | axis) + 1);
-        end_[me] = (int32_t)out_->nodes.size();
-        if (depth + 1 > max_depth) max_depth = depth + 1;
+        return true;
     }
     double split_min_ = 0, split_scale_ = 0;
 public:

@@ -416,10 +416,10 @@ constexpr int BVH_LEAF_SLOTS = 8;         // >= BVH_LEAF_MAX of pt_bvh.hpp (a le
 // `t_best()` is read at every node, so subtrees pushed earlier are pruned against
 // the best hit found since; `leaf(first, cnt)` tests the objects in slots
 // [first, first + cnt) of the leaf-ordered lists.
-template <typename LeafFn, typename BestFn>
+template <typename STK, typename LeafFn, typename BestFn>
 __device__ __forceinline__ void bvh_walk(const float4 *__restrict__ nodes,
                                          float ox, float oy, float oz, float dx, float dy, float dz,
-                                         int *stack, int stride, LeafFn &&leaf, BestFn &&t_best)
+                                         STK *stack, int stride, LeafFn &&leaf, BestFn &&t_best)
 {
     const float ix = __builtin_amdgcn_rcpf(dx), iy = __builtin_amdgcn_rcpf(dy), iz = __builtin_amdgcn_rcpf(dz);
     const uint32_t neg = (dx < 0.f ? 1u : 0u) | (dy < 0.f ? 2u : 0u) | (dz < 0.f ? 4u : 0u);
@@ -431,7 +431,7 @@ __device__ __forceinline__ void bvh_walk(const float4 *__restrict__ nodes,
     auto pop = [&]() -> int {
         if (sp == 0) return -1;
         sp -= 1;
-        return stack[sp * stride];
+        return (int)stack[sp * stride];
     };
     for (;;) {
         int code = -1;
@@ -440,9 +440,9 @@ __device__ __forceinline__ void bvh_walk(const float4 *__restrict__ nodes,
             if (!slab_hit(nd, ox, oy, oz, ix, iy, iz, t_best())) { n = pop(); continue; }
             const int c = __float_as_int(nd.w);
             if (c >= 0) { code = c; break; }
-            const int cc = -(c + 1), right = cc >> 2, left = n + 1;
+            const int cc = -(c + 1), left = cc >> 2, right = left + 1;    // siblings are neighbours (pt_bvh.hpp)
             const bool right_first = (neg >> (cc & 3)) & 1u;
-            stack[sp * stride] = right_first ? left : right;
+            stack[sp * stride] = (STK)(right_first ? left : right);
             sp += 1;
             n = right_first ? right : left;
         }
@@ -452,9 +452,10 @@ __device__ __forceinline__ void bvh_walk(const float4 *__restrict__ nodes,
     }
 }
 
+template <typename STK>
 __device__ inline PrimaryHit primary_hit_f64_bvh(const double *__restrict__ prim, const float4 *__restrict__ nodes,
                                                  const int32_t *__restrict__ prims, int n_unbounded,
-                                                 int H, int W, double camera_depth, int i, int j, int *stack, int stride)
+                                                 int H, int W, double camera_depth, int i, int j, STK *stack, int stride)
 {
 #pragma clang fp contract(off)
     PrimaryHit h;

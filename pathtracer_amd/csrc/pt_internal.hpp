@@ -59,6 +59,7 @@ struct TraceArgs {
     int      n_slices;
     int      slice_j0[MAX_SLICES], slice_n[MAX_SLICES];
     int      n_nodes;
+    int      bvh_cache_nodes;          // trace_bvh_kernel: the first this many nodes (level order: the top of the tree) live in LDS
     int      bvh_depth;                // deepest leaf: the walk's stack holds at most this many far children
     int      n_unbounded;
 };

@@ -655,6 +655,13 @@ __global__ __launch_bounds__(NS == -2 ? 64 : TRACE_BLOCK) void trace_steal_kerne
 // paths, the hits and pt_segments are the same; only WHEN a lane does what
 // changes (and with it the fp32 summation order of a pixel's samples).
 // ---------------------------------------------------------------------------
+// One wave per workgroup.  The kernel can keep the top of the tree (the first bvh_cache_nodes nodes in level order,
+// where every walk starts) in LDS, shared by the waves of a workgroup of any size: pools, stacks and sums are per
+// wave, and only the staging of that copy needs a barrier.  MEASURED (profiles/r02_bvh_roofline.txt), it does not
+// pay: four-wave workgroups with 448-960 cached nodes remove every node gather of the 1,000-object scenes and a
+// third of the 10,000-object scene's, and run 12-50 % SLOWER than one-wave workgroups without a cache (fewer
+// waves per CU, one more LDS round trip per step); 64-128 nodes in a one-wave workgroup: +-3 %.  So the default
+// is no cache, and what this round keeps is the 16-bit stack (2-5 % from the occupancy it frees).
 constexpr int BVH_BLOCK = 64;
 #ifndef PT_BVH_ROUND_VISITS
 #define PT_BVH_ROUND_VISITS 8
@@ -662,18 +669,23 @@ constexpr int BVH_BLOCK = 64;
 #ifndef PT_BVH_SHADE_LANES
 #define PT_BVH_SHADE_LANES 12
 #endif
+constexpr int BVH_CACHE_NODES = 0;      // see BVH_BLOCK
 
-template <bool SPEC>
+template <bool SPEC, typename STK>
 __global__ __launch_bounds__(BVH_BLOCK) void trace_bvh_kernel(TraceArgs a)
 {
     constexpr int BLOCK = BVH_BLOCK;
-    int *const stack = reinterpret_cast<int *>(s_tile) + threadIdx.x;   // [entry][lane], sized by the launcher
+    // dynamic LDS: [top of the tree: bvh_cache_nodes x 16 B][stacks: (bvh_depth + 1) entries x BLOCK lanes x STK]
+    // (STK = 16 bits while the tree has fewer than 65,536 nodes: the stacks are what limits the waves per CU)
+    const float4 *const s_nodes = s_tile;
+    STK *const stack = reinterpret_cast<STK *>(s_tile + a.bvh_cache_nodes) + threadIdx.x;   // [entry][lane]
     __shared__ uint32_t s_next[BLOCK];          // per pixel: next sample (launch-local index) not started
     __shared__ float4   s_pix[BLOCK * 3];       // per pixel: P0, d0, colour0, idx0, e0
     __shared__ float    s_acc[BLOCK * 3];       // per pixel: radiance gathered for it by other lanes
     auto mat = [&](int k, int f) -> float4 { return a.mat[k * 4 + f]; };
 
     const int tid = threadIdx.x;
+    const int wbase = tid & ~63;                           // this wave's first slot in the per-pixel arrays
     const int npix = a.height * a.width;
     const int pixel0 = blockIdx.x * BLOCK;
     const bool in_canvas = pixel0 + tid < npix;
@@ -681,6 +693,7 @@ __global__ __launch_bounds__(BVH_BLOCK) void trace_bvh_kernel(TraceArgs a)
     const int pi = pc / a.width, pj = pc - pi * a.width;
     const uint32_t n = (uint32_t)a.n_samples;
     const int B = a.max_bounces;
+    for (int q = tid; q < a.bvh_cache_nodes; q += BLOCK) s_tile[q] = a.bvh_nodes[q];
 
     uint32_t segs = in_canvas ? 1u : 0u;                   // the fp64 primary search below (a lane runs < 2^32 searches per launch)
     // what bounds this kernel: 16-byte per-lane gathers (one per node visited, three per object record).
@@ -773,7 +786,7 @@ __global__ __launch_bounds__(BVH_BLOCK) void trace_bvh_kernel(TraceArgs a)
     auto pop = [&]() -> int {
         if (wsp == 0) return -1;
         wsp -= 1;
-        return stack[wsp * BLOCK];
+        return (int)stack[wsp * BLOCK];
     };
 
     bool live = traced && n > 0;                           // has a path in flight
@@ -813,7 +826,7 @@ __global__ __launch_bounds__(BVH_BLOCK) void trace_bvh_kernel(TraceArgs a)
                 const bool has = __hip_atomic_load(&s_next[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < n;
                 const unsigned long long avail = __ballot(has);
                 if (avail == 0ull) { dry = true; break; }
-                const int v = __ffsll((long long)avail) - 1;     // wave-uniform choice of pixel to help
+                const int v = wbase + (__ffsll((long long)avail) - 1);     // wave-uniform choice of pixel to help
                 if (needy) {
                     sn = atomicAdd(&s_next[v], 1u);
                     if (sn < n) {
@@ -851,18 +864,19 @@ __global__ __launch_bounds__(BVH_BLOCK) void trace_bvh_kernel(TraceArgs a)
             if (walking) {
                 int code = -1, steps = 0;
                 while (wn >= 0 && steps < PT_BVH_ROUND_VISITS) {
-                    const float4 nd = nodes[wn];
+                    float4 nd;
+                    if (wn < a.bvh_cache_nodes) nd = s_nodes[wn];      // the top of the tree: LDS
+                    else { nd = nodes[wn]; n_nodes_visited += 1u; }    // below it: a gather
                     steps += 1;
                     if (!slab_hit(nd, o.x, o.y, o.z, ix, iy, iz, wbt)) { wn = pop(); continue; }
                     const int c = __float_as_int(nd.w);
                     if (c >= 0) { code = c; break; }
-                    const int cc = -(c + 1), right = cc >> 2, left = wn + 1;
+                    const int cc = -(c + 1), left = cc >> 2, right = left + 1;
                     const bool right_first = (neg >> (cc & 3)) & 1u;
-                    stack[wsp * BLOCK] = right_first ? left : right;
+                    stack[wsp * BLOCK] = (STK)(right_first ? left : right);
                     wsp += 1;
                     wn = right_first ? right : left;
                 }
-                n_nodes_visited += (uint32_t)steps;
                 if (code >= 0) {
                     const int first = code >> 3, cnt = (code & 7) + 1;
                     n_records += 3u * (uint32_t)((cnt + 1) & ~1);     // 16-byte gathers: three per record slot (slots are fetched in pairs)
@@ -886,7 +900,9 @@ __global__ __launch_bounds__(BVH_BLOCK) void trace_bvh_kernel(TraceArgs a)
         }
     }
 
-    __syncthreads();
+    // (no workgroup barrier: a pixel's sum is touched by lanes of its own wave only, and a wave's LDS operations
+    // complete in order -- the other three waves may still be tracing)
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     if (in_canvas) {
         a.canvas[3 * (size_t)pc + 0] = s_acc[tid * 3 + 0];
         a.canvas[3 * (size_t)pc + 1] = s_acc[tid * 3 + 1];
@@ -986,8 +1002,24 @@ static hipError_t launch_trace_ns(TraceArgs a, const float4 *geom_host, bool reu
             const dim3 tgrid((npix + SB - 1) / SB), tblock(SB);
             const size_t ssm = NS == -2 ? (size_t)(a.bvh_depth + 1) * SB * sizeof(int) : 0;
             if (NS == -2 && !getenv("PT_BVH_LOCKSTEP")) {      // (PT_BVH_LOCKSTEP: the one-search-per-trip loop, for A/B)
-                if (spec) hipLaunchKernelGGL((trace_bvh_kernel<true>), tgrid, tblock, ssm, s, a);
-                else      hipLaunchKernelGGL((trace_bvh_kernel<false>), tgrid, tblock, ssm, s, a);
+                // LDS per one-wave workgroup: 4 KB of per-pixel pools (static) + the stacks (2.2 KB at depth 16 with
+                // 16-bit entries; 32-bit entries held the kernel to 19 waves per CU, now its 78 VGPRs do: 24) + the
+                // top of the tree, if any (PT_BVH_CACHE_NODES in the environment, read at every launch, for A/B).
+                const char *ce = getenv("PT_BVH_CACHE_NODES");
+                const int cache_env = ce ? atoi(ce) : -1;
+                const bool s16 = a.n_nodes < 65536;
+                a.bvh_cache_nodes = cache_env >= 0 ? cache_env : BVH_CACHE_NODES;
+                if (a.bvh_cache_nodes > a.n_nodes) a.bvh_cache_nodes = a.n_nodes;
+                const dim3 bgrid((npix + BVH_BLOCK - 1) / BVH_BLOCK), bblock(BVH_BLOCK);
+                const size_t bsm = (size_t)a.bvh_cache_nodes * sizeof(float4) +
+                                   (size_t)(a.bvh_depth + 1) * BVH_BLOCK * (s16 ? sizeof(uint16_t) : sizeof(int));
+                if (s16) {
+                    if (spec) hipLaunchKernelGGL((trace_bvh_kernel<true, uint16_t>), bgrid, bblock, bsm, s, a);
+                    else      hipLaunchKernelGGL((trace_bvh_kernel<false, uint16_t>), bgrid, bblock, bsm, s, a);
+                } else {
+                    if (spec) hipLaunchKernelGGL((trace_bvh_kernel<true, int>), bgrid, bblock, bsm, s, a);
+                    else      hipLaunchKernelGGL((trace_bvh_kernel<false, int>), bgrid, bblock, bsm, s, a);
+                }
                 return hipGetLastError();
             }
             if (spec) hipLaunchKernelGGL((trace_steal_kernel<NS, true>), tgrid, tblock, ssm, s, a, sg, a.geom);

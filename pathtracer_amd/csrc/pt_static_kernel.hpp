@@ -30,7 +30,8 @@ __device__ __forceinline__ unsigned long long *seg_lane(unsigned long long *base
 }
 
 // the per-pixel fp64 primary segment, through the spatial index when the scene has one
-__device__ __forceinline__ PrimaryHit primary_hit(const TraceArgs &a, int pi, int pj, int *stack = nullptr, int stride = 0)
+template <typename STK = int>
+__device__ __forceinline__ PrimaryHit primary_hit(const TraceArgs &a, int pi, int pj, STK *stack = nullptr, int stride = 0)
 {
     if (a.n_nodes > 0 && stack)
         return primary_hit_f64_bvh(a.prim, a.bvh_nodes, a.bvh_prims, a.n_unbounded, a.height, a.width,

@@ -216,15 +216,18 @@ def test_rgb8_of_full_canvas(pa):
 # an hour per GPU), so it runs at its full image size, object count and depth with 256 spp (the spatial index makes that seconds;
 # the full 4096 spp would be about a minute and a half on one GPU).
 
-def _spot_check_scene(pa, H, W, objs, spp, bounces, cam, count, seed):
+def _spot_check_scene(pa, H, W, objs, spp, bounces, cam, count, seed, chunk=None):
     rng = np.random.default_rng(seed)
     px = np.unique(np.concatenate([rng.integers(0, H * W, count),
                                    [0, W - 1, (H - 1) * W, H * W - 1, 63, 64, 255, 256, H * W - 65]])).astype(np.int32)
     with pa.Renderer(pa.Params(H, W, cam, spp, bounces), objs, seed=1) as r:
-        r.trace(spp)
+        for _ in range(spp // (chunk or spp)):             # (launches of a second or two each)
+            r.trace(chunk or spp)
+            r.synchronize()
+        assert r.samples_done == spp
         dev = r.read_sum().reshape(-1, 3)
         segs = r.segments
-    ora, _ = O.trace_pixels(O.params(H, W, cam, bounces, O.PHILOX, 1), O.scene_from(objs), px, spp)
+    ora, _ = O.trace_pixels(O.params(H, W, cam, bounces, O.PHILOX, 1), O.scene_from(objs), px, spp, threads=16)
     d = dev[px]
     rel = np.abs(d - ora) / np.maximum(np.abs(ora), 1e-9)
     close = ((rel <= 1e-3) | (np.abs(d - ora) <= 1e-4)).all(axis=1)
@@ -245,6 +248,15 @@ def test_config4_thousand_disks_full_size(pa):
 def test_config5_ten_thousand_disks_full_image_reduced_spp(pa):
     objs = pa.synthetic_scene(10000, 2, "disks")
     _spot_check_scene(pa, 3840, 2160, objs, 256, 16, 500.0, 40, 45)
+
+
+def test_config5_as_written_4096_spp_depth_16_on_one_gpu(pa):
+    """BASELINE.json configs[4] at its stated size -- 10,000 objects, 3840x2160, 4096 spp, depth 16 -- on ONE GPU
+    (the configuration names 8; the sample split only divides these launches among ranks): 3.4e10 paths, about a
+    quarter of a minute of kernels, spot-checked against the oracle on the same Philox stream."""
+    objs = pa.synthetic_scene(10000, 2, "disks")
+    segs = _spot_check_scene(pa, 3840, 2160, objs, 4096, 16, 500.0, 4, 46, chunk=256)
+    assert segs > 3840 * 2160 * 4096
 
 
 def test_statistical_parity_at_bench_resolution(pa):

@@ -628,3 +628,23 @@ def test_spatial_index_with_coincident_and_degenerate_disks(pa):
     assert np.allclose(res[0][0], res[1][0], rtol=2e-6, atol=1e-6) and np.allclose(res[0][0], res[2][0], rtol=2e-6, atol=1e-6)
     assert np.array_equal(res[0][2], res[1][2]) and np.array_equal(res[2][2], res[3][2])
     assert not np.isin(res[0][2], [60, 61, 62]).any()       # a duplicate never wins over object 5
+
+
+def test_spatial_index_with_its_top_levels_in_lds(pa, monkeypatch):
+    """PT_BVH_CACHE_NODES (an A/B switch, off by default: DESIGN.md 3.4) keeps the first nodes of the level-ordered
+    tree in LDS; the walk must find exactly what it finds without it."""
+    objs = pa.random_disk_scene(1025, 10)
+    P = pa.Params(96, 80, 500.0, 6, 5)
+    def render():
+        with pa.Renderer(P, objs, seed=2) as r:
+            r.trace(6)
+            return r.read_sum_f32(), r.segments, r.bvh_counters()
+    monkeypatch.delenv("PT_BVH_CACHE_NODES", raising=False)
+    a, sa, (na, ra) = render()
+    monkeypatch.setenv("PT_BVH_CACHE_NODES", "100")
+    b, sb, (nb, rb) = render()
+    assert sa == sb and ra == rb and 0 < nb < na          # same searches, same records, fewer node gathers
+    assert np.allclose(a, b, rtol=4e-6, atol=1e-6)         # (the order lanes finish in may differ: fp32 summation order)
+    with pa.Renderer(P, objs, seed=2, flags=pa.PT_FLAG_NO_BVH) as r:
+        r.trace(6)
+        assert r.segments == sa and r.bvh_counters() == (0, 0)
