@@ -191,6 +191,12 @@ def main():
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: libpt has no CPU path")
+    # PT_BENCH_REHEARSE_ONE_GPU=1: every rank on device 0 and NO collective (RCCL refuses two ranks on one device):
+    # a rehearsal of the N > 1 control flow -- launcher, gloo rendezvous, sample split, fences, max of the time, sum
+    # of the segments -- on a one-GPU box.  The line it prints says so and is not a measurement.
+    rehearsal = os.environ.get("PT_BENCH_REHEARSE_ONE_GPU") == "1" and world > 1
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     # PT_BENCH_FORCE_DIST=1 drives the collective path with a world of 1 (rehearsal on a 1-GPU box)
@@ -242,7 +248,7 @@ def main():
     # machine every rank falls back to torch's all-reduce together, and the JSON line says which one ran.
     collective, comm = None, {}
     if multi:
-        collective = args.collective
+        collective = "none (rehearsal on one GPU: frames are NOT combined)" if rehearsal else args.collective
         if collective == "libpt":
             ok = 1
             try:
@@ -262,6 +268,8 @@ def main():
             nccl_group = dist.new_group(backend="nccl")
 
     def allreduce(q, cv):
+        if rehearsal:
+            return None
         if collective == "libpt":
             q.allreduce_sum()                           # ncclAllReduce on the context's stream, into its total
             return None
@@ -361,7 +369,7 @@ def main():
                        "collective": None if not multi else
                                      (f"libpt ncclAllReduce behind the C ABI (pt_allreduce_sum), {comm.get('n_ranks')} RCCL ranks, "
                                       f"RCCL version code {comm.get('rccl_version')}" if collective == "libpt"
-                                      else "torch.distributed all_reduce (nccl = RCCL)"),
+                                      else "torch.distributed all_reduce (nccl = RCCL)" if collective == "torch" else collective),
                        "value_mode": "wall time of K pipelined frames (barrier + device synchronize on both sides, "
                                      "max over ranks); consecutive frames overlap on two streams"
                                      if pipe is not None else "wall time of K in-line frames",
