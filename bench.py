@@ -205,6 +205,11 @@ def main():
         import torch.distributed as dist
         if "MASTER_ADDR" not in os.environ:
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
+        if os.environ["MASTER_ADDR"] in ("127.0.0.1", "localhost"):
+            # one node: RCCL's and gloo's bootstrap sockets on the loopback interface, whatever else the box has
+            # (data moves over xGMI / shared memory either way); an interface named by the caller wins
+            os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
         dist.init_process_group("gloo")          # control plane only: the RCCL id, barriers, max of the time
 
     my_spp, s_off, s_stride = shard_samples(args.spp, rank, world)
