@@ -23,6 +23,18 @@ def global_samples(total_spp: int, rank: int, world: int):
     return [off + k * stride for k in range(count)]
 
 
+def block_samples(done: int, iters: int, member: int, members: int) -> Tuple[int, int]:
+    """-> (first sample index k, count) of `member`'s share of one pt_trace(iters) call on a pt_create_multi
+    context whose group has rendered `done` samples so far: contiguous blocks, sizes differing by at most one,
+    their union the call's range [done, done + iters) whatever the number of members.  The host-side mirror of
+    group_trace (pathtracer_amd/csrc/pt_multi.hip), for tests and for hosts that schedule devices themselves."""
+    if members < 1 or not 0 <= member < members or iters < 0 or done < 0:
+        raise ValueError("need members >= 1, 0 <= member < members, iters >= 0, done >= 0")
+    base, rem = divmod(iters, members)
+    first = done + member * base + min(member, rem)
+    return first, base + (1 if member < rem else 0)
+
+
 def allreduce_canvas(canvas, group=None):
     """In-place sum of the radiance canvas over all ranks (torch tensor on the
     rank's GPU for the nccl(=RCCL) backend, CPU tensor under gloo)."""

@@ -69,3 +69,35 @@ def test_shard_samples_partition():
             assert sum(counts) == total and max(counts) - min(counts) <= 1
     with pytest.raises(ValueError):
         shard_samples(8, 2, 2)
+
+
+def test_device_group_block_split_renders_the_same_frame():
+    """pt_create_multi's split (contiguous blocks of every pt_trace call, pt_multi.hip group_trace; mirrored by
+    block_samples): the blocks of a call tile its range for any group size, and the oracle rendering each block on
+    the Philox stream sums to the one-device frame -- over several calls, including calls of fewer samples than members."""
+    import oracle as O
+    from pathtracer_amd.distributed import block_samples
+    for done, iters in ((0, 0), (0, 1), (3, 2), (0, 1024), (5, 7), (100, 1023)):
+        for members in (1, 2, 3, 5, 8):
+            blocks = [block_samples(done, iters, m, members) for m in range(members)]
+            assert sum(c for _, c in blocks) == iters
+            nxt = done
+            for first, count in blocks:
+                assert first == nxt and count in (iters // members, iters // members + 1)
+                nxt += count
+    H, W, B = 20, 28, 6
+    p = O.params(H, W, 500.0, B, O.PHILOX, 3)
+    whole = O.Tracer(p, O.default_scene(), threads=1)
+    members = 3
+    parts = [O.Tracer(p, O.default_scene(), threads=1) for _ in range(members)]
+    done = 0
+    for iters in (5, 1, 7, 2):                           # four pt_trace calls on the group
+        whole.trace(iters)
+        for m, tr in enumerate(parts):
+            first, count = block_samples(done, iters, m, members)
+            if count:
+                tr.trace(count, s_begin=first)
+        done += iters
+    total = sum(tr.sum for tr in parts)
+    assert np.allclose(total, whole.sum, rtol=1e-12, atol=1e-12)
+    assert sum(tr.segments.value for tr in parts) == whole.segments.value
