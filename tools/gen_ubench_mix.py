@@ -238,18 +238,43 @@ def per_instruction(loop):
         R = Renamer()
         body = [rename_keep_pattern(text, R) for _ in range(32)]
         names.append((f"k{k}", text))
-        print(f"__global__ __launch_bounds__(64) void k{k}(int trips)\n{{\n    asm volatile(\n{asm_block(init)}\n"
+        print(f"__global__ __launch_bounds__(64) void k{k}(int trips, long long *clk)\n{{\n"
+              f"    const long long c0 = clock64(), w0 = wall_clock64();\n    asm volatile(\n{asm_block(init)}\n"
               f'        "s_mov_b32 s62, %0\\n\\t"\n        "1:\\n\\t"\n{asm_block(body)}\n'
               f'        "s_sub_u32 s62, s62, 1\\n\\t"\n        "s_cmp_lg_u32 s62, 0\\n\\t"\n        "s_cbranch_scc1 1b\\n\\t"\n'
-              f"        : : \"s\"(trips) : {clob});\n}}\n")
-    print("int main(int argc, char **argv)\n{\n    const int trips = argc > 1 ? atoi(argv[1]) : 4000;\n"
-          "    hipDeviceProp_t p; hipGetDeviceProperties(&p, 0);\n    const int grid = p.multiProcessorCount * 4 * 8;\n"
-          "    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);\n    double total = 0;")
+              f"        : : \"s\"(trips) : {clob});\n"
+              f"    const long long c1 = clock64(), w1 = wall_clock64();\n"
+              f"    if (threadIdx.x == 0) {{ clk[2 * blockIdx.x] = c1 - c0; clk[2 * blockIdx.x + 1] = w1 - w0; }}\n}}\n")
+    print("""
+// shader clocks (s_memtime) and 100 MHz wall ticks (s_memrealtime) taken by every wave around its loop: the cycles are
+// counted, not derived from a nominal frequency; the frequency the chip actually ran at falls out as cycles / wall time
+static void clocks(const long long *h, int grid, double *cycles, double *ghz)
+{
+    int khz = 100000; hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, 0);
+    double c = 0, w = 0;
+    for (int k = 0; k < grid; ++k) { c += (double)h[2 * k]; w += (double)h[2 * k + 1]; }
+    *cycles = c / grid; *ghz = c / w * (khz * 1e-6);
+}
+
+int main(int argc, char **argv)
+{
+    const int rounds = 8;                                // workgroups per wave slot: the dispatcher evens out the SIMDs (a grid of
+                                                         // exactly one workgroup per slot fills them unevenly and reads 10-20 % high)
+    const int trips = (argc > 1 ? atoi(argv[1]) : 4000) / rounds;
+    hipDeviceProp_t p; hipGetDeviceProperties(&p, 0);
+    const int grid = p.multiProcessorCount * 4 * 8 * rounds;
+    long long *clk, *h = (long long *)malloc(sizeof(long long) * 2 * grid);
+    hipMalloc(&clk, sizeof(long long) * 2 * grid);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    double total = 0, total_counted = 0;
+    printf("# cycles per wave-instruction per SIMD (kernel time by HIP events x the shader clock measured in the kernel) | that clock, GHz | instruction\\n");""")
     for name, text in names:
-        print(f'    {{ hipLaunchKernelGGL({name}, dim3(grid), dim3(64), 0, 0, trips / 4); hipDeviceSynchronize(); float best = 1e30f;\n'
-              f'      for (int r = 0; r < 3; ++r) {{ hipEventRecord(e0, 0); hipLaunchKernelGGL({name}, dim3(grid), dim3(64), 0, 0, trips); hipEventRecord(e1, 0); hipEventSynchronize(e1); float ms; hipEventElapsedTime(&ms, e0, e1); if (ms < best) best = ms; }}\n'
-              f'      const double cyc = best * 1e-3 * 2.4e9 / ((double)trips * 8 * 32); total += cyc; printf("%6.2f  %s\\n", cyc, "{text}"); }}')
-    print('    printf("%6.2f  = sum over the VALU instructions of the loop (cycles per wave-instruction per SIMD at 2.4 GHz, 8 waves per SIMD)\\n", total);\n    return 0;\n}')
+        print(f'    {{ hipLaunchKernelGGL({name}, dim3(grid), dim3(64), 0, 0, trips / 4, clk); hipDeviceSynchronize(); float best = 1e30f;\n'
+              f'      for (int r = 0; r < 3; ++r) {{ hipEventRecord(e0, 0); hipLaunchKernelGGL({name}, dim3(grid), dim3(64), 0, 0, trips, clk); hipEventRecord(e1, 0); hipEventSynchronize(e1); float ms; hipEventElapsedTime(&ms, e0, e1); if (ms < best) best = ms; }}\n'
+              f'      hipMemcpy(h, clk, sizeof(long long) * 2 * grid, hipMemcpyDeviceToHost); double cy, ghz; clocks(h, grid, &cy, &ghz);\n'
+              f'      const double cyc = best * 1e-3 * ghz * 1e9 / ((double)trips * rounds * 8 * 32); total += cyc;\n'
+              f'      printf("%6.2f  %5.3f  %s\\n", cyc, ghz, "{text}"); }}')
+    print('    printf("%6.2f  = sum over the VALU instructions of the loop (8 waves per SIMD, %d workgroups per wave slot)\\n", total, rounds);\n    (void)total_counted;\n    return 0;\n}')
 
 
 def main():
@@ -279,9 +304,10 @@ def main():
 
     def kernel(name, body):
         return f"""
-__global__ __launch_bounds__(64) void {name}(int trips, float *sink)
+__global__ __launch_bounds__(64) void {name}(int trips, float *sink, long long *clk)
 {{
     __shared__ float lds[1088];                       // 4.25 KB (the shipped offsets reach 4084 + 16): 32 workgroups per CU fit the 160 KB
+    const long long c0 = clock64(), w0 = wall_clock64();
     asm volatile(
 {asm_block(init)}
         "s_mov_b32 s62, %0\\n\\t"
@@ -291,6 +317,8 @@ __global__ __launch_bounds__(64) void {name}(int trips, float *sink)
         "s_cmp_lg_u32 s62, 0\\n\\t"
         "s_cbranch_scc1 1b\\n\\t"
         : : "s"(trips) : {clob});
+    const long long c1 = clock64(), w1 = wall_clock64();
+    if (threadIdx.x == 0) {{ clk[2 * blockIdx.x] = c1 - c0; clk[2 * blockIdx.x + 1] = w1 - w0; }}
     if (trips < 0) sink[0] = lds[0];
 }}
 """
@@ -310,9 +338,10 @@ __global__ __launch_bounds__(64) void {name}(int trips, float *sink)
         for k in range(1, 8):
             entry += [f"s_cmp_eq_u32 s63, {k}", f"s_cbranch_scc1 L{k}_%="]
         return f"""
-__global__ __launch_bounds__(64) void {name}(int trips, float *sink)
+__global__ __launch_bounds__(64) void {name}(int trips, float *sink, long long *clk)
 {{
     __shared__ float lds[1088];                       // 4.25 KB: 32 workgroups per CU fit the 160 KB
+    const long long c0 = clock64(), w0 = wall_clock64();
     asm volatile(
 {asm_block(init)}
         "s_mov_b32 s62, %0\\n\\t"
@@ -322,6 +351,8 @@ __global__ __launch_bounds__(64) void {name}(int trips, float *sink)
         "s_cmp_lg_u32 s62, 0\\n\\t"
         "s_cbranch_scc1 L0_%=\\n\\t"
         : : "s"(trips), "s"(blockIdx.x) : {clob});
+    const long long c1 = clock64(), w1 = wall_clock64();
+    if (threadIdx.x == 0) {{ clk[2 * blockIdx.x] = c1 - c0; clk[2 * blockIdx.x + 1] = w1 - w0; }}
     if (trips < 0) sink[0] = lds[0];
 }}
 """
@@ -342,34 +373,83 @@ __global__ __launch_bounds__(64) void {name}(int trips, float *sink)
     print(kernel("only_plain", by["plain"]))
     print(kernel("only_second", by["second"]))
     print(kernel("only_trans", by["trans"] * 4))
+
+    # what the scalar instructions between the vector ones are worth: the same VALU streams with one SALU instruction
+    # (independent, on scratch registers) after every m-th VALU instruction
+    def with_salu(body, every):
+        out = []
+        for k, t in enumerate(body):
+            out.append(t)
+            if (k + 1) % every == 0:
+                out.append(f"s_and_b64 s[{40 + 2 * (k % 8)}:{41 + 2 * (k % 8)}], s[56:57], s[58:59]")
+        return out
+    extra = []
+    for nm, body in (("valu", valu), ("plain", by["plain"]), ("second", by["second"]), ("trans", by["trans"] * 4), ("grouped", by["plain"] + by["second"] + by["trans"])):
+        for every in (1, 2, 4):
+            extra.append((f"{nm}_salu{every}", nm, every))
+            print(kernel(f"{nm}_salu{every}", with_salu(body, every)))
+    # which classes overlap: pairs of classes in the shipped relative order, with and without the scalar instructions
+    for nm, keep in (("plain_second", ("plain", "second")), ("plain_trans", ("plain", "trans")), ("second_trans", ("second", "trans"))):
+        body = [t for t in valu if classify(t) in keep]
+        for every in (0, 2):
+            extra.append((f"{nm}_salu{every}", nm, every))
+            print(kernel(f"{nm}_salu{every}", with_salu(body, every) if every else body))
+    extra.append(("spread_salu2", "spread", 2))
+    print(kernel("spread_salu2", with_salu(spread_valu, 2)))
+    no_lds = [t for t in shipped if not t.startswith(("ds_", "s_waitcnt"))]
+    print(kernel("shipped_no_lds", no_lds))
+    only_lds = [t for t in shipped if t.startswith(("ds_", "s_waitcnt", "v_"))]
+    print(kernel("valu_and_lds", only_lds))
     print(f"""
 #define CK(x) do {{ hipError_t e_ = (x); if (e_ != hipSuccess) {{ fprintf(stderr, "%s: %s\\n", #x, hipGetErrorString(e_)); return 1; }} }} while (0)
 
+// shader clocks (s_memtime) and 100 MHz wall ticks (s_memrealtime) taken by every wave around its loop: the cycles are
+// counted, not derived from a nominal frequency; the frequency the chip actually ran at falls out as cycles / wall time
+static void clocks(const long long *h, int grid, double *cycles, double *ghz)
+{{
+    int khz = 100000; hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, 0);
+    double c = 0, w = 0;
+    for (int k = 0; k < grid; ++k) {{ c += (double)h[2 * k]; w += (double)h[2 * k + 1]; }}
+    *cycles = c / grid; *ghz = c / w * (khz * 1e-6);
+}}
+
+
+static int g_rounds = 1;      // workgroups per wave slot: > 1 lets the dispatcher even out the SIMDs, as the real kernel's 32,400 workgroups do
+
 template <typename K> static int run(const char *name, K kern, int trips, int waves_per_simd, int simds, float *sink)
 {{
+    static long long *clk = nullptr, *h = nullptr;
+    const size_t cap = (size_t)2 * simds * 8 * g_rounds;
+    if (!clk) {{ CK(hipMalloc(&clk, sizeof(long long) * cap)); h = (long long *)malloc(sizeof(long long) * cap); }}
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    const int grid = simds * waves_per_simd;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(64), 0, 0, trips / 8, sink);       // warm-up
+    const int grid = simds * waves_per_simd * g_rounds;
+    trips /= g_rounds;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64), 0, 0, trips / 8, sink, clk);       // warm-up
     CK(hipDeviceSynchronize());
     float best = 1e30f;
     for (int rep = 0; rep < 5; ++rep) {{
         CK(hipEventRecord(e0, 0));
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(64), 0, 0, trips, sink);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(64), 0, 0, trips, sink, clk);
         CK(hipEventRecord(e1, 0));
         CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         if (ms < best) best = ms;
     }}
-    const double ns_per_trip = best * 1e6 / ((double)trips * waves_per_simd);
-    printf("%-12s %d waves/SIMD  %8.3f ms  %7.2f ns per trip per SIMD  (= %.1f cycles at 2.4 GHz, %.1f at 2.3)\\n",
-           name, waves_per_simd, best, ns_per_trip, ns_per_trip * 2.4, ns_per_trip * 2.3);
+    const double ns_per_trip = best * 1e6 / ((double)trips * g_rounds * waves_per_simd);
+    CK(hipMemcpy(h, clk, sizeof(long long) * 2 * grid, hipMemcpyDeviceToHost));
+    double cy, ghz; clocks(h, grid, &cy, &ghz);
+    // a wave's own clocks per trip = what its SIMD needed for one trip of each of the waves it held meanwhile
+    printf("%-14s %d waves/SIMD x %2d rounds  %8.3f ms  %7.2f ns per trip per SIMD = %6.1f cycles at the measured %.3f GHz;  mean wave: %6.1f clocks per trip of its own\\n",
+           name, waves_per_simd, g_rounds, best, ns_per_trip, ns_per_trip * ghz, ghz, cy / (double)trips);
     return 0;
 }}
 
 int main(int argc, char **argv)
 {{
     const int trips = argc > 1 ? atoi(argv[1]) : 40000;
+    g_rounds = argc > 2 ? atoi(argv[2]) : 1;
+    if (g_rounds < 1 || g_rounds > 64) return 2;
     hipDeviceProp_t p; CK(hipGetDeviceProperties(&p, 0));
     const int simds = p.multiProcessorCount * 4;
     float *sink; CK(hipMalloc(&sink, 4096));
@@ -385,6 +465,10 @@ int main(int argc, char **argv)
         if (run("only_plain", only_plain, trips, w, simds, sink)) return 1;
         if (run("only_second", only_second, trips, w, simds, sink)) return 1;
         if (run("only_trans x4", only_trans, trips, w, simds, sink)) return 1;
+        if (w != 8) continue;
+        if (run("shipped_no_lds", shipped_no_lds, trips, w, simds, sink)) return 1;
+        if (run("valu_and_lds", valu_and_lds, trips, w, simds, sink)) return 1;
+{chr(10).join(f'        if (run("{n}", {n}, trips, w, simds, sink)) return 1;' for n, _, _ in extra)}
     }}
     return 0;
 }}
