@@ -106,6 +106,21 @@ hipFunction_t jit_static_kernel(int device, int n_obj, bool spec, const float4 *
     if (it != g_cache.end()) return it->second.fn;
 
     Rtc &r = rtc();
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) { (void)hipGetLastError(); err = "hipGetDeviceProperties failed"; return nullptr; }
+    const std::string arch = std::string("--offload-arch=") + prop.gcnArchName;
+    std::vector<char> code;
+    // PT_SCENE_KERNEL_CO: a code object built outside (experiments on the kernel's assembly, tools/rebank.py)
+    if (const char *co = getenv("PT_SCENE_KERNEL_CO")) {
+        if (FILE *f = std::fopen(co, "rb")) {
+            char buf[65536];
+            size_t got;
+            while ((got = std::fread(buf, 1, sizeof buf, f)) > 0) code.insert(code.end(), buf, buf + got);
+            std::fclose(f);
+        }
+        if (code.empty()) { err = std::string("PT_SCENE_KERNEL_CO: cannot read ") + co; return nullptr; }
+    }
+    if (code.empty()) {
     if (!r.ok) { err = "libhiprtc.so not found or incomplete"; return nullptr; }
 
     std::string src = "#define PT_JIT 1\n#define PT_JIT_NS " + std::to_string(NS) + "\n#define PT_JIT_SPEC " +
@@ -130,9 +145,6 @@ hipFunction_t jit_static_kernel(int device, int n_obj, bool spec, const float4 *
     const char *names[] = {"pt_static_kernel.hpp", "pt_internal.hpp", "pt_device.hpp"};
     rtc_program prog = nullptr;
     if (r.create(&prog, src.c_str(), "pt_scene_kernel.hip", 3, headers, names) != 0) { err = "hiprtcCreateProgram failed"; return nullptr; }
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device) != hipSuccess) { (void)hipGetLastError(); r.destroy(&prog); err = "hipGetDeviceProperties failed"; return nullptr; }
-    std::string arch = std::string("--offload-arch=") + prop.gcnArchName;
     std::vector<const char *> opts = {arch.c_str(), "-O3", "-std=c++17", "-fno-slp-vectorize"};   // the Makefile's code-generation flags
     // PT_JIT_FLAGS: further compiler options, separated by blanks (scheduling experiments; part of the cache key)
     std::vector<std::string> extra;
@@ -156,9 +168,10 @@ hipFunction_t jit_static_kernel(int device, int n_obj, bool spec, const float4 *
     }
     size_t n = 0;
     r.code_size(prog, &n);
-    std::vector<char> code(n);
+    code.resize(n);
     r.code(prog, code.data());
     r.destroy(&prog);
+    }
 
     Entry e;
     hipError_t he = hipModuleLoadData(&e.mod, code.data());

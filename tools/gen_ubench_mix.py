@@ -191,7 +191,7 @@ def asm_block(lines):
     return "\n".join(f'        "{ln}\\n\\t"' for ln in lines)
 
 
-def rename_keep_pattern(text, R):
+def rename_keep_pattern(text, R, mod=24):
     """Like rename(), but a VGPR source keeps its identity: vN -> v(N mod 24), so an operand used twice in the
     shipped instruction is used twice here, and register parities survive (24 is even)."""
     op, _, rest = text.partition(" ")
@@ -213,7 +213,7 @@ def rename_keep_pattern(text, R):
         if core == "vcc":
             new = "vcc"
         elif mv:
-            new = f"v{int(mv.group(1)) % 24}"
+            new = f"v{int(mv.group(1)) % mod}"
         elif core.startswith("s["):
             new = "s[56:57]"
         elif re.match(r"s\d+$", core):
@@ -298,6 +298,15 @@ def main():
             valu.append(new)
             counts[classify(new)] += 1
     spread_valu = spread(valu)
+    # the shipped loop once more, with the VGPR sources in the banks the compiler put them in (vN -> v(N mod 24):
+    # parities and repeated operands survive), so that its same-bank multiply-adds are in the replay too
+    Rb = Renamer()
+    banked = []
+    for text in loop:
+        kind, new = rename(text, Rb)
+        if new is None:
+            continue
+        banked.append(rename_keep_pattern(text, Rb) if kind == "valu" else new)
     clob = ", ".join([f'"v{k}"' for k in range(60)] + [f'"s{k}"' for k in range(36, 64)] + ['"vcc"', '"scc"', '"memory"'])
     init = ["v_mov_b32 v31, 0"] + [f"v_mov_b32 v{k}, 0x3fc00000" for k in range(31)] + \
            ["s_mov_b64 s[56:57], -1", "s_mov_b64 s[58:59], -1", "s_mov_b32 s60, 0", "s_mov_b32 s61, 0"]
@@ -364,6 +373,7 @@ __global__ __launch_bounds__(64) void {name}(int trips, float *sink, long long *
     print("// Build: hipcc -O3 --offload-arch=gfx950 -o ubench_mix ubench_mix.hip    Run: ./ubench_mix [trips]")
     print("#include <hip/hip_runtime.h>\n#include <cstdio>\n#include <cstdlib>\n")
     print(kernel("mix_shipped", shipped))
+    print(kernel("mix_banked", banked))
     print(kernel("mix_valu", valu))
     print(kernel("mix_spread", spread_valu))
     print(kernel_phased("phased_shipped", shipped))
@@ -457,6 +467,7 @@ int main(int argc, char **argv)
            p.gcnArchName, p.multiProcessorCount);
     for (int w : {{8, 7, 4}}) {{
         if (run("mix_shipped", mix_shipped, trips, w, simds, sink)) return 1;
+        if (run("mix_banked", mix_banked, trips, w, simds, sink)) return 1;
         if (run("mix_valu", mix_valu, trips, w, simds, sink)) return 1;
         if (run("mix_spread", mix_spread, trips, w, simds, sink)) return 1;
         if (run("phased_shipped", phased_shipped, trips, w, simds, sink)) return 1;
