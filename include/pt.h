@@ -135,7 +135,10 @@ void pt_destroy(pt_ctx *ctx);
 
 /* Replaces the top-level value Object.objects (src/Object.hs:147-148).  Copies
  * and flattens `n` objects to the device SoA; index order is preserved because
- * closestObjectTo breaks ties by position (src/Lib.hs:84).  1 <= n <= 65536. */
+ * closestObjectTo breaks ties by position (src/Lib.hs:84).  0 <= n <= 65536;
+ * n = 0 (objs may be NULL) is the empty object list: closestObjectTo's guard
+ * (src/Lib.hs:83) answers Nothing for every ray, so every sample is black and
+ * pt_segments counts the one search per pixel that finds nothing. */
 int pt_scene_upload(pt_ctx *ctx, const pt_object *objs, int32_t n);
 
 /* The synthetic n-object scenes of BASELINE.json configs[3]/[4], generated as

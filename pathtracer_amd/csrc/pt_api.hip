@@ -260,8 +260,9 @@ int pt_scene_upload(pt_ctx *c, const pt_object *objs, int32_t n)
 {
     if (int s = check_ctx(c)) return s;
     if (c->group) return group_scene_upload(c, objs, n);
-    if (!objs) return fail(c, PT_ERR_INVALID, "pt_scene_upload: null objects");
-    if (n < 1 || n > MAX_OBJECTS) return fail(c, PT_ERR_LIMIT, "pt_scene_upload: need 1 <= n <= 65536");
+    // n = 0 is the reference's empty object list: closestObjectTo's guard (src/Lib.hs:83) answers Nothing, every sample is black
+    if (n < 0 || n > MAX_OBJECTS) return fail(c, PT_ERR_LIMIT, "pt_scene_upload: need 0 <= n <= 65536");
+    if (!objs && n > 0) return fail(c, PT_ERR_INVALID, "pt_scene_upload: null objects");
     for (int k = 0; k < n; ++k)
         if (objs[k].kind != PT_INFINITE_PLANE && objs[k].kind != PT_DISK && objs[k].kind != PT_SPHERE && objs[k].kind != PT_RECTANGLE)
             return fail(c, PT_ERR_INVALID, "pt_scene_upload: unknown Form kind");
@@ -269,13 +270,13 @@ int pt_scene_upload(pt_ctx *c, const pt_object *objs, int32_t n)
     // 8 trailing records that can never be hit (n = 0 gives t = NaN): the
     // streamed closest-hit loop works in groups of 4 and prefetches one group ahead
     constexpr int GEOM_PAD = 8;
-    std::vector<float4> geom((size_t)(n + GEOM_PAD) * 3), mat((size_t)n * 4);
+    std::vector<float4> geom((size_t)(n + GEOM_PAD) * 3), mat((size_t)(n > 0 ? n : 1) * 4);   // (never empty: hipMalloc(0))
     for (int k = n; k < n + GEOM_PAD; ++k) {
         geom[(size_t)k * 3 + 0] = make_float4(0.f, 0.f, 0.f, 0.f);
         geom[(size_t)k * 3 + 1] = make_float4(0.f, 0.f, 0.f, std::numeric_limits<float>::infinity());
         geom[(size_t)k * 3 + 2] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    std::vector<double> prim((size_t)n * PRIM_DOUBLES);
+    std::vector<double> prim((size_t)(n > 0 ? n : 1) * PRIM_DOUBLES);
     bool spec = false, has_rect = false;
     for (int k = 0; k < n; ++k) has_rect = has_rect || objs[k].kind == PT_RECTANGLE;
     std::vector<float4> rect(has_rect ? (size_t)n * 2 : 0);
@@ -299,6 +300,7 @@ int pt_scene_upload(pt_ctx *c, const pt_object *objs, int32_t n)
     if (c->d_bvh_geom) { (void)hipFree(c->d_bvh_geom); c->d_bvh_geom = nullptr; }
     c->n_nodes = c->n_unbounded = 0;
     c->n_obj = 0;
+    c->have_scene = false;
     c->pix_valid = false;
     PT_HIP(c, hipMalloc((void **)&c->d_geom, geom.size() * sizeof(float4)));
     PT_HIP(c, hipMalloc((void **)&c->d_mat, mat.size() * sizeof(float4)));
@@ -313,6 +315,7 @@ int pt_scene_upload(pt_ctx *c, const pt_object *objs, int32_t n)
     c->h_geom = geom;
     c->scene_kernel = nullptr;                   // belongs to the previous scene
     c->n_obj = n;
+    c->have_scene = true;
     c->has_specular = spec;
 
     // Spatial index over the finite forms, for scenes beyond the by-value list.
@@ -398,7 +401,7 @@ int pt_trace(pt_ctx *c, int32_t iters)
 int pt::trace_block(pt_ctx *c, int64_t k_begin, int32_t iters)
 {
     if (int s = check_ctx(c)) return s;
-    if (c->n_obj < 1) return fail(c, PT_ERR_NO_SCENE, "pt_trace: no scene uploaded");
+    if (!c->have_scene) return fail(c, PT_ERR_NO_SCENE, "pt_trace: no scene uploaded");
     if (iters < 0 || k_begin < 0) return fail(c, PT_ERR_INVALID, "pt_trace: iters < 0");
     c->total_valid = false;
     const int64_t last_global =
@@ -459,7 +462,7 @@ int pt_scene_specialise(pt_ctx *c)
 {
     if (int s = check_ctx(c)) return s;
     if (c->group) return group_scene_specialise(c);
-    if (c->n_obj < 1) return fail(c, PT_ERR_NO_SCENE, "pt_scene_specialise: no scene uploaded");
+    if (!c->have_scene) return fail(c, PT_ERR_NO_SCENE, "pt_scene_specialise: no scene uploaded");
     if (c->n_obj > MAX_STATIC_OBJECTS)
         return fail(c, PT_ERR_UNSUPPORTED, "pt_scene_specialise: only scenes of <= 8 objects have a kernel to specialise");
     if (c->p.flags & (PT_FLAG_NO_STEAL | PT_FLAG_NO_PRIMARY_REUSE))
@@ -615,7 +618,7 @@ int pt_primary_hits(pt_ctx *c, int32_t *idx, double *t, double *normal)
         if (s) c->err = m->err;
         return s;
     }
-    if (c->n_obj < 1) return fail(c, PT_ERR_NO_SCENE, "pt_primary_hits: no scene uploaded");
+    if (!c->have_scene) return fail(c, PT_ERR_NO_SCENE, "pt_primary_hits: no scene uploaded");
     // device staging for the three outputs (4 + 8 + 24 bytes per pixel), allocated once per context
     const size_t n = npix(c);
     if (!c->d_hits) PT_HIP(c, hipMalloc(&c->d_hits, n * 36));

@@ -31,6 +31,7 @@ struct pt_ctx {
     uint8_t *d_rgb = nullptr;
     void *d_hits = nullptr;            // device staging of pt_primary_hits (idx, t, normal: 36 B per pixel), kept between calls
     int n_obj = 0;
+    bool have_scene = false;           // pt_scene_upload has run (an EMPTY scene is a scene: src/Lib.hs:83, every ray misses)
     bool has_specular = false;
     std::vector<float4> h_geom;         // host copy: small scenes ride in the kernel arguments
     hipFunction_t scene_kernel = nullptr;   // trace_static_kernel compiled for this scene (pt_scene_specialise), or null

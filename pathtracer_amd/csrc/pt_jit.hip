@@ -89,7 +89,7 @@ std::map<std::string, Entry> g_cache;      // (device, NS, SPEC, geometry bits) 
 
 hipFunction_t jit_static_kernel(int device, int n_obj, bool spec, const float4 *geom_host, std::string &err)
 {
-    if (n_obj < 1 || n_obj > MAX_STATIC_OBJECTS) { err = "more objects than the by-value kernel takes"; return nullptr; }
+    if (n_obj < 0 || n_obj > MAX_STATIC_OBJECTS) { err = "more objects than the by-value kernel takes"; return nullptr; }
     const int NS = n_obj <= 4 ? 4 : MAX_STATIC_OBJECTS;
     // the geometry exactly as launch_trace_ns pads it
     std::vector<float> g((size_t)NS * 12, 0.0f);

@@ -1007,7 +1007,7 @@ static hipError_t launch_trace_ns(TraceArgs a, const float4 *geom_host, bool reu
                 // top of the tree, if any (PT_BVH_CACHE_NODES in the environment, read at every launch, for A/B).
                 const char *ce = getenv("PT_BVH_CACHE_NODES");
                 const int cache_env = ce ? atoi(ce) : -1;
-                const bool s16 = a.n_nodes < 65536;
+                const bool s16 = a.n_nodes < 65536 && !getenv("PT_BVH_STACK32");   // (PT_BVH_STACK32: the 32-bit form for any tree, A/B and tests)
                 a.bvh_cache_nodes = cache_env >= 0 ? cache_env : BVH_CACHE_NODES;
                 if (a.bvh_cache_nodes > a.n_nodes) a.bvh_cache_nodes = a.n_nodes;
                 const dim3 bgrid((npix + BVH_BLOCK - 1) / BVH_BLOCK), bblock(BVH_BLOCK);

@@ -156,7 +156,7 @@ int group_trace(pt_ctx *head, int32_t iters)
         const int32_t cnt = base + (i < rem ? 1 : 0);
         pt_ctx *m = g->members[i];
         if (cnt == 0) {                              // (a member that sits a call out must still hold a scene)
-            if (m->n_obj < 1) return fail(head, PT_ERR_NO_SCENE, "pt_trace: no scene uploaded");
+            if (!m->have_scene) return fail(head, PT_ERR_NO_SCENE, "pt_trace: no scene uploaded");
             continue;
         }
         if (int s = up(head, m, trace_block(m, k, cnt))) return s;

@@ -507,8 +507,10 @@ def test_error_behaviour(pa):
     with pa.Renderer(pa.Params(8, 8, 500.0, 1, 4)) as r:
         with pytest.raises(pa.PtError):
             r.trace(-1)
-        with pytest.raises(pa.PtError):
-            r.upload([])
+        r.upload([])                                       # the empty object list is a scene (src/Lib.hs:83; tested below)
+        with pytest.raises(pa.PtError) as e:
+            _ = pa._lib.check(pa._lib.lib.pt_scene_upload(r._ctx, None, 3), r._ctx)     # null objects with n > 0
+        assert e.value.status == pa._lib.PT_ERR_INVALID
 
 
 def test_sample_index_limit_and_the_last_usable_samples(pa):
@@ -648,3 +650,98 @@ def test_spatial_index_with_its_top_levels_in_lds(pa, monkeypatch):
     with pa.Renderer(P, objs, seed=2, flags=pa.PT_FLAG_NO_BVH) as r:
         r.trace(6)
         assert r.segments == sa and r.bvh_counters() == (0, 0)
+
+
+def test_spatial_index_with_32_bit_stacks(pa, monkeypatch):
+    """The walk's per-lane stack holds 16-bit node numbers while the tree has fewer than 65,536 nodes (LDS per wave
+    is what it saves); PT_BVH_STACK32 selects the 32-bit form that larger trees take.  Same walk, same result."""
+    objs = pa.random_disk_scene(2000, 12)
+    P = pa.Params(80, 96, 500.0, 5, 6)
+    def render(flags):
+        with pa.Renderer(P, objs, seed=4, flags=flags) as r:
+            r.trace(5)
+            return r.read_sum_f32(), r.segments, r.bvh_counters()
+    monkeypatch.delenv("PT_BVH_STACK32", raising=False)
+    a, sa, ca = render(0)
+    monkeypatch.setenv("PT_BVH_STACK32", "1")
+    b, sb, cb = render(0)
+    assert sa == sb and ca == cb and ca[0] > 0
+    assert np.allclose(a, b, rtol=4e-6, atol=1e-6)          # (the order lanes finish in may differ: fp32 summation order)
+    scan, ss, _ = render(pa.PT_FLAG_NO_BVH)
+    assert ss == sa and np.allclose(scan, b, rtol=4e-6, atol=1e-6)
+
+
+# ------------------------------------------------- empty and maximum scenes ----
+@pytest.mark.parametrize("flags_name", ["0", "PT_FLAG_NO_STEAL", "PT_FLAG_NO_PRIMARY_REUSE", "PT_FLAG_LDS_TILES"])
+def test_empty_scene_is_black(pa, flags_name):
+    """`objects = []`: closestObjectTo's guard (src/Lib.hs:83) answers Nothing for every ray, interactWith Nothing is
+    black (src/Lib.hs:72).  One search per pixel runs and finds nothing; the oracle says the same."""
+    flags = 0 if flags_name == "0" else getattr(pa, flags_name)
+    H, W = 70, 130
+    with pa.Renderer(pa.Params(H, W, 500.0, 4, 8), [], seed=1, flags=flags) as r:
+        r.trace(3)
+        r.trace(1)
+        assert r.samples_done == 4
+        assert not r.read_sum_f32().any()
+        # executed searches: the primary one -- once per pixel (kept for the scene), once per pixel and launch in
+        # the strict-order kernels, once per pixel and sample without the reuse
+        per_pixel = {"0": 1, "PT_FLAG_NO_STEAL": 2, "PT_FLAG_LDS_TILES": 1, "PT_FLAG_NO_PRIMARY_REUSE": 4}[flags_name]
+        assert r.segments == H * W * per_pixel
+        assert not r.read_rgb8(pa.PT_RGB8_REFERENCE).any()
+        idx, t, nrm = r.primary_hits()
+        if flags == 0:
+            r.specialise()                                  # an empty scene has a scene kernel too (all padding)
+            r.reset()
+            r.trace(2)
+            assert not r.read_sum_f32().any() and r.segments == 0       # (the kept primary hits: no search runs)
+    empty = (O.OObject * 0)()
+    p = O.params(H, W, 500.0, 8, O.PHILOX, 1)
+    oidx, ot, _ = O.primary_hits(p, empty)
+    assert np.array_equal(idx, oidx) and (idx == -1).all()
+    assert np.array_equal(t, ot)
+    ora = O.Tracer(p, empty, threads=2)
+    assert not ora.trace(4).any() and ora.segments.value == H * W * 4     # the oracle searches for every sample (no reuse)
+
+
+def test_scene_changes_to_and_from_the_empty_scene(pa):
+    H, W = 64, 64
+    with pa.Renderer(pa.Params(H, W, 500.0, 2, 8), seed=2) as r:          # the default scene
+        r.trace(2)
+        lit = r.read_sum_f32()
+        assert lit.any()
+        r.upload([])
+        r.reset()
+        r.trace(2)
+        assert not r.read_sum_f32().any() and r.segments == H * W
+        r.upload(pa.objects)
+        r.reset()
+        r.trace(2)
+        assert np.array_equal(r.read_sum_f32(), lit)
+
+
+def test_limit_of_65536_objects(pa):
+    """MAX_OBJECTS (include/pt.h): 65,536 objects upload, index and render -- checked against the oracle's scan on
+    its Philox stream at a small frame -- and one more is refused."""
+    n = 65536
+    objs = pa.synthetic_scene(n, 5, "disks")
+    H, W, spp, B = 48, 64, 2, 6
+    with pa.Renderer(pa.Params(H, W, 500.0, spp, B), objs, seed=3) as r:
+        r.trace(spp)
+        dev = r.read_sum()
+        segs = r.segments
+        idx, t, _ = r.primary_hits()
+        nodes, _ = r.bvh_counters()
+        assert nodes > 0                                    # it went through the index
+        with pytest.raises(pa.PtError) as e:
+            r.upload(list(objs) + [objs[0]])
+        assert e.value.status == pa.PT_ERR_LIMIT
+        r.trace(1)                                          # the refused upload left the scene in place
+    p = O.params(H, W, 500.0, B, O.PHILOX, 3)
+    sc = O.scene_from(objs)
+    oidx, ot, _ = O.primary_hits(p, sc)
+    assert np.array_equal(idx, oidx) and np.array_equal(t, ot)
+    tr = O.Tracer(p, sc, threads=8)
+    ora = tr.trace(spp)
+    assert tr.segments.value - H * W * spp == segs - H * W   # the oracle also counts each sample's primary search
+    bad = (np.abs(dev - ora) > 2e-4 * np.abs(ora) + 1e-5).any(axis=2).mean()
+    assert bad <= 0.01
