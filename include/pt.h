@@ -283,6 +283,11 @@ int pt_scene_specialise(pt_ctx *ctx);
  * hiprtc, which lacks it; the kernel then uses a v_cndmask_b32 form of the
  * same decision).  Empty when the general kernel is in use. */
 int pt_jit_info(pt_ctx *ctx, char *buf, size_t size);
+/* How many scene kernels the process holds loaded right now.  A kernel is shared
+ * by every context with that scene on that device, stays loaded after its last
+ * user has gone (the next one skips the compile), and is unloaded once more
+ * than 16 unused ones have piled up, least recently used first. */
+int pt_jit_cache_size(void);
 
 /* Last kernel's launch duration in milliseconds, measured with HIP events on
  * the context's stream around the most recent pt_trace (all its launches).

@@ -235,6 +235,7 @@ void pt_destroy(pt_ctx *c)
     if (c->group) { group_destroy(c); delete c; return; }
     (void)hipSetDevice(c->p.device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    jit_release(c->scene_kernel);
     if (c->d_canvas) (void)hipFree(c->d_canvas);
     if (c->d_segments) (void)hipFree(c->d_segments);
     if (c->d_geom) (void)hipFree(c->d_geom);
@@ -313,7 +314,8 @@ int pt_scene_upload(pt_ctx *c, const pt_object *objs, int32_t n)
         PT_HIP(c, hipMemcpy(c->d_rect, rect.data(), rect.size() * sizeof(float4), hipMemcpyHostToDevice));
     }
     c->h_geom = geom;
-    c->scene_kernel = nullptr;                   // belongs to the previous scene
+    jit_release(c->scene_kernel);                // belongs to the previous scene (the stream was drained above)
+    c->scene_kernel = nullptr;
     c->n_obj = n;
     c->have_scene = true;
     c->has_specular = spec;
@@ -470,9 +472,15 @@ int pt_scene_specialise(pt_ctx *c)
     std::string why;
     hipFunction_t fn = jit_static_kernel(c->p.device, c->n_obj, c->has_specular, c->h_geom.data(), why);
     if (!fn) return fail(c, PT_ERR_UNSUPPORTED, "pt_scene_specialise: " + why + " (the general kernel stays in use)");
+    if (c->scene_kernel) {                       // called again (normally the same kernel): give the earlier hold back
+        PT_HIP(c, hipStreamSynchronize(c->stream));
+        jit_release(c->scene_kernel);
+    }
     c->scene_kernel = fn;
     return PT_OK;
 }
+
+int pt_jit_cache_size(void) { return jit_cache_size(); }
 
 int pt_jit_info(pt_ctx *c, char *buf, size_t size)
 {

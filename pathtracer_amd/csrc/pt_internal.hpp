@@ -92,6 +92,10 @@ namespace pt {
 hipFunction_t jit_static_kernel(int device, int n_obj, bool spec, const float4 *geom_host, std::string &err);
 // what compiled it: "hiprtc <major>.<minor> (<library file>), --offload-arch=..., __builtin_amdgcn_inverse_ballot_w64 available|missing"
 std::string jit_kernel_info(hipFunction_t fn);
+// A context that stops using a kernel from jit_static_kernel (scene change, pt_destroy) gives it back -- after its
+// stream has drained.  Unused kernels beyond a small number are unloaded.
+void jit_release(hipFunction_t fn);
+int jit_cache_size();
 #endif
 
 } // namespace pt

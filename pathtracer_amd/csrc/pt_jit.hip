@@ -81,9 +81,35 @@ Rtc &rtc()
     return r;
 }
 
-struct Entry { hipModule_t mod = nullptr; hipFunction_t fn = nullptr; std::string info; };
+struct Entry {
+    hipModule_t mod = nullptr; hipFunction_t fn = nullptr; std::string info;
+    int device = 0;
+    int users = 0;                 // contexts that hold `fn` (jit_static_kernel hands it out, jit_release takes it back)
+    uint64_t stamp = 0;            // last hand-out, for the eviction order
+};
 std::mutex g_mu;
-std::map<std::string, Entry> g_cache;      // (device, NS, SPEC, geometry bits) -> loaded kernel; lives until exit
+std::map<std::string, Entry> g_cache;      // (device, NS, SPEC, geometry bits) -> loaded kernel
+uint64_t g_clock = 0;
+// Kernels nobody holds stay loaded (the next context with that scene skips the 0.7-s compile) up to this many;
+// beyond it the least recently handed-out unused ones are unloaded (hipModuleUnload).
+constexpr size_t JIT_CACHE_KEEP = 16;
+
+void evict_unused_locked()
+{
+    while (g_cache.size() > JIT_CACHE_KEEP) {
+        auto victim = g_cache.end();
+        for (auto it = g_cache.begin(); it != g_cache.end(); ++it)
+            if (it->second.users == 0 && (victim == g_cache.end() || it->second.stamp < victim->second.stamp)) victim = it;
+        if (victim == g_cache.end()) return;               // every kernel is in use
+        int cur = 0;
+        (void)hipGetDevice(&cur);
+        (void)hipSetDevice(victim->second.device);
+        (void)hipModuleUnload(victim->second.mod);
+        (void)hipSetDevice(cur);
+        (void)hipGetLastError();
+        g_cache.erase(victim);
+    }
+}
 
 } // namespace
 
@@ -103,7 +129,7 @@ hipFunction_t jit_static_kernel(int device, int n_obj, bool spec, const float4 *
 
     std::lock_guard<std::mutex> lock(g_mu);
     auto it = g_cache.find(key);
-    if (it != g_cache.end()) return it->second.fn;
+    if (it != g_cache.end()) { it->second.users += 1; it->second.stamp = ++g_clock; return it->second.fn; }
 
     Rtc &r = rtc();
     hipDeviceProp_t prop;
@@ -194,8 +220,25 @@ hipFunction_t jit_static_kernel(int device, int n_obj, bool spec, const float4 *
     }
     e.info = r.where + ", " + arch + ", __builtin_amdgcn_inverse_ballot_w64 " +
              (has == 1 ? "available" : has == 0 ? "missing (v_cndmask_b32 form)" : "unknown");
+    e.device = device; e.users = 1; e.stamp = ++g_clock;
     g_cache.emplace(std::move(key), e);
+    evict_unused_locked();
     return e.fn;
+}
+
+void jit_release(hipFunction_t fn)
+{
+    if (!fn) return;
+    std::lock_guard<std::mutex> lock(g_mu);
+    for (auto &kv : g_cache)
+        if (kv.second.fn == fn) { if (kv.second.users > 0) kv.second.users -= 1; break; }
+    evict_unused_locked();
+}
+
+int jit_cache_size()
+{
+    std::lock_guard<std::mutex> lock(g_mu);
+    return (int)g_cache.size();
 }
 
 std::string jit_kernel_info(hipFunction_t fn)

@@ -172,6 +172,11 @@ class Renderer:
         check(lib.pt_comm_info(self._ctx, C.byref(a), C.byref(b), C.byref(c), C.byref(d)), self._ctx)
         return {"n_ranks": a.value, "rank": b.value, "n_local": c.value, "rccl_version": d.value}
 
+    @staticmethod
+    def jit_cache_size() -> int:
+        """pt_jit_cache_size: scene kernels the process holds loaded."""
+        return lib.pt_jit_cache_size()
+
     def specialise(self) -> bool:
         """pt_scene_specialise: compile the trace kernel for this scene (seconds; worth it for a scene that is
         traced for a while).  True if the scene kernel is now in use, False if the library reported that the

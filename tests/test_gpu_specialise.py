@@ -90,3 +90,40 @@ def test_where_it_does_not_apply(pa):
     with pa.Renderer(P, pa.objects, flags=pa.PT_FLAG_NO_STEAL) as r:
         assert not r.specialise()
         r.trace(4)
+
+
+def test_scene_kernels_are_shared_kept_and_unloaded(pa):
+    """The kernel cache (pt_jit.hip): contexts with one scene share one kernel; a kernel nobody holds stays loaded
+    until more than 16 unused ones have piled up, then the least recently used go (hipModuleUnload); a kernel in use
+    is never unloaded, however many there are."""
+    P = pa.Params(32, 64, 500.0, 2, 4)
+    def scene(k):                                           # distinct geometry per k
+        return [pa.Object((1, 1, 1), 0.0, False, pa.InfinitePlane((0.0, 0.0, 100.0 + k), (0.0, 0.0, -1.0)), "wall"),
+                pa.Object((1, 1, 1), 2.0, True, pa.Disk((0.0, 0.0, -1.0), (0.0, 0.0, 1.0), 20.0), "light")]
+    with pa.Renderer(P, scene(0)) as a, pa.Renderer(P, scene(0)) as b:
+        if not a.specialise():
+            pytest.skip("pt_scene_specialise not available: " + a.last_error())
+        base = pa.Renderer.jit_cache_size()
+        assert b.specialise() and pa.Renderer.jit_cache_size() == base          # the same kernel
+        assert a.specialise() and pa.Renderer.jit_cache_size() == base          # asked twice: still one hold
+        a.trace(2); b.trace(2)
+        assert np.array_equal(a.read_sum_f32(), b.read_sum_f32())
+    held = []
+    try:
+        for k in range(1, 20):                              # 19 more scenes, all in use at once
+            r = pa.Renderer(P, scene(k))
+            assert r.specialise()
+            held.append(r)
+        assert pa.Renderer.jit_cache_size() >= 19           # none of them may go
+        for r in held:
+            r.trace(1)
+            assert r.read_sum_f32().any()
+    finally:
+        for r in held:
+            r.close()
+    assert pa.Renderer.jit_cache_size() <= 16               # released: trimmed to what is kept for the next user
+    with pa.Renderer(P, scene(19)) as r:                    # the most recent one is still there (no compile: same count)
+        n = pa.Renderer.jit_cache_size()
+        assert r.specialise() and pa.Renderer.jit_cache_size() == n
+        r.trace(2)
+        assert r.read_sum_f32().any()
