@@ -1,0 +1,85 @@
+"""tools/rebank.py (no GPU): the register re-allocation of the trace loop against VGPR bank conflicts, run on the
+default scene's kernel as hipcc compiles it.  The tool is an experiment's instrument (the conflicts
+turned out not to matter in the mix), so what is checked is that it does what it says: fewer same-bank
+multiply-adds, every other instruction untouched, and assembly that still assembles."""
+import os
+import re
+import shutil
+import struct
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIPCC = "/opt/rocm/bin/hipcc"
+LLVM = "/opt/rocm/lib/llvm/bin"
+
+pytestmark = pytest.mark.skipif(not (os.path.exists(HIPCC) and os.path.exists(os.path.join(LLVM, "clang"))),
+                                reason="needs hipcc and the ROCm llvm tools")
+
+
+def scene_source():
+    inf = float("inf")
+    objs = [[0, 0, -1, -100, 0, 0, -1, inf, 0, 0, 100, 0], [0, 1, 0, -20, 0, 1, 0, inf, 0, -20, 0, 0],
+            [-1, 0, 0, -20, -1, 0, 0, inf, 20, 0, 0, 0], [0, 0, 1, -1, 0, 0, 1, 400, 0, 0, -1, 0]]
+    bits = lambda f: struct.unpack("<I", struct.pack("<f", f))[0]
+    geom = ",".join("{" + ",".join(f"PT_JIT_F(0x{bits(x):08x}u)" for x in o) + "}" for o in objs)
+    return ("#define PT_JIT 1\n#define PT_JIT_NS 4\n#define PT_JIT_SPEC 0\n#define PT_JIT_F(x) __builtin_bit_cast(float, x)\n"
+            f"#define PT_JIT_GEOM {{{geom}}}\n#include \"pt_static_kernel.hpp\"\n")
+
+
+def same_bank(lines):
+    n = 0
+    for ln in lines:
+        m = re.match(r"\s+(v_fma_f32|v_fmac_f32_e32|v_fmaak_f32)\s+v\d+, -?v(\d+), -?v(\d+)", ln)
+        if m and m.group(2) != m.group(3) and (int(m.group(2)) ^ int(m.group(3))) & 1 == 0:
+            n += 1
+        m = re.match(r"\s+v_fmac_f32_e32\s+v\d+, v(\d+), v(\d+)", ln)
+        if m and m.group(1) == m.group(2):
+            n += 1
+    return n
+
+
+def test_rebank_reduces_conflicts_and_still_assembles(tmp_path):
+    src = tmp_path / "scene.hip"
+    src.write_text(scene_source())
+    asm, out = tmp_path / "scene.s", tmp_path / "scene_rb.s"
+    subprocess.run([HIPCC, "-O3", "-std=c++17", "-fno-slp-vectorize", "--offload-arch=gfx950", "--cuda-device-only", "-S",
+                    "-I" + os.path.join(ROOT, "pathtracer_amd", "csrc"), "-o", str(asm), str(src)],
+                   check=True, capture_output=True, timeout=300)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rebank.py"), str(asm), str(out)],
+                       check=True, capture_output=True, text=True, timeout=300)
+    assert "nothing done" not in p.stderr, p.stderr
+    a, b = asm.read_text().split("\n"), out.read_text().split("\n")
+    # the loop: between the tool's note and the backward branch that follows it
+    start = next(k for k, ln in enumerate(b) if "rebank.py" in ln)
+    label = next(ln for ln in b[start:] if ln.startswith(".LBB")).split(":")[0]
+    end = next(k for k in range(start, len(b)) if re.match(r"\s+s_cbranch_scc\d\s+" + re.escape(label) + r"\b", b[k]))
+    a0 = next(k for k, ln in enumerate(a) if ln.startswith(label + ":"))
+    a1 = next(k for k in range(a0, len(a)) if re.match(r"\s+s_cbranch_scc\d\s+" + re.escape(label) + r"\b", a[k]))
+    before, after = same_bank(a[a0:a1]), same_bank(b[start:end])
+    assert before >= 6 and after <= before - 4, (before, after, p.stderr)
+    # same instructions in the same order: only register numbers differ (and v_fmac d,x,x became v_fma d,x,x,d)
+    ops = lambda ls: [ln.split()[0].replace("v_fmac_f32_e32", "v_fma_f32") for ln in ls
+                      if ln.startswith("\t") and not ln.strip().startswith((";", "."))]
+    lb0 = next(k for k, ln in enumerate(b) if ln.startswith(label + ":"))
+    assert ops(a[a0 + 1:a1]) == ops(b[lb0 + 1:end])
+    # outside the loop: only the tool's note and moves in front of it, its moves behind it, and the register count
+    move = re.compile(r"\tv_(mov_b32_e32|swap_b32) v\d+, v\d+$")
+    assert b[:start] == a[:a0] and all(move.match(ln) for ln in b[start + 1:lb0])
+    n_post = 0
+    while move.match(b[end + 1 + n_post]):
+        n_post += 1
+    count = re.compile(r"\s*\.(amdhsa_next_free_vgpr|vgpr_count:)")
+    assert [ln for ln in b[end + 1 + n_post:] if not count.match(ln)] == [ln for ln in a[a1 + 1:] if not count.match(ln)]
+    assert lb0 - start - 1 >= 1 and n_post >= 1
+    for f in (asm, out):
+        obj = str(f) + ".o"
+        subprocess.run([os.path.join(LLVM, "clang"), "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950",
+                        "-c", str(f), "-o", obj], check=True, capture_output=True, timeout=120)
+        subprocess.run([os.path.join(LLVM, "ld.lld"), "-shared", obj, "-o", obj + ".co"], check=True, capture_output=True, timeout=120)
+        assert os.path.getsize(obj + ".co") > 4096
+    m = re.search(r"\.amdhsa_next_free_vgpr\s+(\d+)", out.read_text())
+    assert int(m.group(1)) <= 64                             # still 8 waves per SIMD
+    shutil.rmtree(tmp_path, ignore_errors=True)
