@@ -794,9 +794,16 @@ __global__ __launch_bounds__(BVH_BLOCK) void trace_bvh_kernel(TraceArgs a)
     if (live) { d = scatter(cidx, ce, cd0, 0, cP0); begin_search(); walking = true; }
     bool dry = false;                                      // wave-uniform: no pixel has an unstarted sample
 
+#ifdef PT_BVH_CLOCKS
+    long long clk_shade = 0, clk_walk = 0, n_shade = 0, n_walk = 0;
+#endif
     for (;;) {
         const unsigned long long wm = __ballot(walking), rm = __ballot(ready);
         if (wm == 0ull && rm == 0ull) break;
+#ifdef PT_BVH_CLOCKS
+        const long long c_in = clock64();
+        const bool shading = rm != 0ull && (wm == 0ull || __popcll(rm) >= PT_BVH_SHADE_LANES);
+#endif
         if (rm != 0ull && (wm == 0ull || __popcll(rm) >= PT_BVH_SHADE_LANES)) {
             // ---- shade: the lanes whose search has finished ----------------------
             int k = -1; float t = 0.f;
@@ -898,6 +905,9 @@ __global__ __launch_bounds__(BVH_BLOCK) void trace_bvh_kernel(TraceArgs a)
                 if (wn < 0) { walking = false; ready = true; }
             }
         }
+#ifdef PT_BVH_CLOCKS
+        { const long long dc = clock64() - c_in; if (shading) { clk_shade += dc; n_shade += 1; } else { clk_walk += dc; n_walk += 1; } }
+#endif
     }
 
     // (no workgroup barrier: a pixel's sum is touched by lanes of its own wave only, and a wave's LDS operations
@@ -909,6 +919,11 @@ __global__ __launch_bounds__(BVH_BLOCK) void trace_bvh_kernel(TraceArgs a)
         a.canvas[3 * (size_t)pc + 2] = s_acc[tid * 3 + 2];
     }
     unsigned long long wsegs = segs, wnodes = n_nodes_visited, wrecs = n_records;
+#ifdef PT_BVH_CLOCKS
+    wnodes = (tid & 63) == 0 ? (unsigned long long)clk_shade : 0ull;      // experiment: clocks in shade / walk steps
+    wrecs = (tid & 63) == 0 ? (unsigned long long)clk_walk : 0ull;
+    (void)n_shade; (void)n_walk;
+#endif
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         wsegs += __shfl_down(wsegs, off, 64);
