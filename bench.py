@@ -158,11 +158,24 @@ def main():
                     help="keep the general trace kernel: no pt_scene_specialise (kernel compiled for the scene) at set-up")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="trace, all-reduce and output strictly in line instead of overlapped with the next frame")
+    ap.add_argument("--watchdog-s", type=float, default=900.0,
+                    help="end the process (exit status 124, a line on stderr) if it has not finished by then: a rank stuck in a "
+                         "rendezvous or a collective must not hold its GPU until somebody else's limit; 0 = off")
     ap.add_argument("--collective", choices=("libpt", "torch"), default="libpt",
                     help="N > 1: libpt's own ncclAllReduce behind the C ABI (default) or torch.distributed's")
     args = ap.parse_args()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(self_launch(args.gpus, sys.argv[1:]))
+    if args.watchdog_s > 0:
+        import threading
+
+        def expire():
+            print(f"bench.py: rank {os.environ.get('RANK', '0')}: not finished after {args.watchdog_s:.0f} s, giving up "
+                  "(--watchdog-s)", file=sys.stderr, flush=True)
+            os._exit(124)
+        dog = threading.Timer(args.watchdog_s, expire)
+        dog.daemon = True
+        dog.start()
     # stdout carries exactly ONE line, the JSON: anything a library prints to file descriptor 1
     # (RCCL's start-up banner does) goes to stderr instead
     json_out = os.fdopen(os.dup(1), "w")

@@ -48,3 +48,21 @@ def test_self_launch_reports_a_dead_rank():
                        env=env, capture_output=True, text=True, timeout=300)
     assert p.returncode != 0
     assert p.stdout.strip() == ""
+
+
+def test_a_rank_that_never_gets_its_peers_gives_up():
+    """--watchdog-s: a rank stuck in a rendezvous (here: a world of 2 of which only rank 0 exists) ends itself with
+    status 124 and a line on stderr instead of holding its GPU until somebody else's limit."""
+    import socket
+    import time
+    import bench
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = bench.rank_environments(2, port)[0]
+    env.update(PT_BENCH_DRY_RUN="1", GLOO_SOCKET_IFNAME="lo")
+    t0 = time.time()
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--watchdog-s", "4"], env=env,
+                       capture_output=True, text=True, timeout=120)
+    assert p.returncode == 124 and "giving up" in p.stderr
+    assert p.stdout.strip() == "" and time.time() - t0 < 60
