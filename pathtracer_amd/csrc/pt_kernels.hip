@@ -890,7 +890,10 @@ __global__ __launch_bounds__(BVH_BLOCK) void trace_bvh_kernel(TraceArgs a)
 #pragma unroll 1
                     for (int h = 0; h < BVH_LEAF_SLOTS; h += 2) {
                         // (fetching a record's third vector only where its plane distance can still win saves 10 % of
-                        // the gathers and costs 4.5 % in time -- a second dependent round trip per pair; measured, dropped)
+                        // the gathers and costs 4.5 % in time -- a second dependent round trip per pair; measured, dropped.
+                        // Not fetching the pair's second slot when the leaf's count is odd saves 5-9 % of the gathers and
+                        // changes the time by -1...+3 %, as constants under a lane mask (82 VGPRs) or as a single record
+                        // behind the pairs; measured, dropped: profiles/r02_bvh_roofline.txt)
                         float4 r[2][3];
 #pragma unroll
                         for (int q = 0; q < 2; ++q) {
