@@ -156,6 +156,9 @@ def main():
     ap.add_argument("--no-bvh", action="store_true", help="PT_FLAG_NO_BVH: linear scan over all objects")
     ap.add_argument("--no-specialise", action="store_true",
                     help="keep the general trace kernel: no pt_scene_specialise (kernel compiled for the scene) at set-up")
+    ap.add_argument("--pipeline-depth", type=int, default=2, choices=(2, 3),
+                    help="frames in flight (canvases and trace streams).  3 measured 1-4 %% slower than 2 on one GPU with "
+                         "libpt's all-reduce over a world of 1 in the loop (tools/pipeline_depth_ab.sh, DESIGN.md 6)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="trace, all-reduce and output strictly in line instead of overlapped with the next frame")
     ap.add_argument("--watchdog-s", type=float, default=900.0,
@@ -243,8 +246,9 @@ def main():
     stream = torch.cuda.Stream()
     torch.cuda.set_stream(stream)
     pipelined = not args.no_pipeline         # the same frame loop for every N; N = 1 simply has no all-reduce
+    depth = args.pipeline_depth
     rs = [pa.Renderer(P, scene, seed=0, device=local_rank, sample_offset=s_off, sample_stride=s_stride,
-                      flags=flags) for _ in range(2 if pipelined else 1)]
+                      flags=flags) for _ in range(depth if pipelined else 1)]
     # set-up, like the scene upload: the trace kernel compiled for this scene (pt_scene_specialise; by-value
     # scenes on the default flags only -- elsewhere, or without hiprtc on the machine, the general kernel stays)
     specialised = False
@@ -320,7 +324,7 @@ def main():
         step()
     fence()
     if pipe is not None:
-        r = rs[(pipe.k - 1) & 1]               # the context of the last frame: its counter holds one step
+        r = rs[(pipe.k - 1) % len(rs)]          # the context of the last frame: its counter holds one step
     segs_step = torch.tensor([r.segments], dtype=torch.float64)
 
     fence()
@@ -391,8 +395,8 @@ def main():
                        "value_mode": "wall time of K pipelined frames (barrier + device synchronize on both sides, "
                                      "max over ranks); consecutive frames overlap on two streams"
                                      if pipe is not None else "wall time of K in-line frames",
-                       "frame_pipeline": "double-buffered: all-reduce + output of frame k overlap the trace of "
-                                         "frame k+1" if pipe is not None else "none"},
+                       "frame_pipeline": f"{len(rs)} frames in flight ({len(rs)} canvases and trace streams): all-reduce + output "
+                                         "of frame k overlap the trace of the next" if pipe is not None else "none"},
             "roofline": {"bound": "valu", "achieved": round(achieved, 3), "peak": FP32_VALU_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / FP32_VALU_PEAK_TFLOPS, 4),
                          "traffic": traffic,

@@ -55,7 +55,7 @@ def canvas_tensor(renderer, device_index: int):
     return torch.as_tensor(_Canvas(), device=torch.device("cuda", device_index))
 
 
-def stream_on_another_queue(first, tries=8, spin_cycles=2_000_000):
+def stream_on_another_queue(first, tries=8, spin_cycles=2_000_000, also=()):
     """A new torch stream whose work runs CONCURRENTLY with `first`'s.  HIP maps
     streams onto a few hardware queues (GPU_MAX_HW_QUEUES, 4 by default) and two
     streams that share one execute in order, however independent their work:
@@ -65,30 +65,34 @@ def stream_on_another_queue(first, tries=8, spin_cycles=2_000_000):
     probes: a ~1-ms spin on both streams takes one spin's time if they overlap
     and two if they do not; streams that do not are kept alive (so the runtime
     hands out another queue next time) and returned for the caller to hold.
-    Falls back to the last stream tried."""
+    `also`: further streams the new one must run concurrently with (a third
+    trace stream against the first two).  Falls back to the last stream tried."""
     import torch
     spare = []
     s = None
     if not hasattr(torch.cuda, "_sleep"):               # no spin kernel to probe with: take what the runtime gives
         return torch.cuda.Stream(), spare
-    for _ in range(tries):
-        s = torch.cuda.Stream()
+    def concurrent(a, s):
         t = []
         for both in (False, False, True):               # the first pass warms up (first use of a stream is slow)
             torch.cuda.synchronize()
             e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
-            e0.record(first)
+            e0.record(a)
             s.wait_event(e0)
-            with torch.cuda.stream(first):
+            with torch.cuda.stream(a):
                 torch.cuda._sleep(spin_cycles)
-                e1.record(first)
+                e1.record(a)
             if both:
                 with torch.cuda.stream(s):
                     torch.cuda._sleep(spin_cycles)
             e2.record(s)
             torch.cuda.synchronize()
             t.append(max(e0.elapsed_time(e1), e0.elapsed_time(e2)))
-        if t[2] < 1.5 * t[1]:
+        return t[2] < 1.5 * t[1]
+
+    for _ in range(tries):
+        s = torch.cuda.Stream()
+        if all(concurrent(a, s) for a in (first, *also)):
             return s, spare
         spare.append(s)
     return s, spare
@@ -101,13 +105,17 @@ class PipelinedFrames:
     output (a side stream) are still in flight, so the collective's time is
     hidden behind the next frame's kernel instead of added to it, and the two
     frames' trace kernels run on two streams so that one's tail overlaps the
-    other's head.  Every frame
+    other's head.  With three renderers the frames rotate over three canvases
+    and three trace streams: a collective that is slow to get CUs next to a
+    trace kernel (it sits on its frame's trace stream, in front of that
+    stream's next frame) then delays nothing until it takes two frames' time.
+    Every frame
     is still one pt_reset + pt_trace + ONE all-reduce + the output kernel; only
     their placement on streams changes.  `drain()` waits for everything.
 
-    renderers: two contexts on this rank's GPU with identical parameters and
-    scene; canvases: their device canvases as torch tensors (canvas_tensor);
-    rgb: two device uint8 buffers (rank 0 only, else None).
+    renderers: two (or three) contexts on this rank's GPU with identical
+    parameters and scene; canvases: their device canvases as torch tensors
+    (canvas_tensor); rgb: as many device uint8 buffers (rank 0 only, else None).
     """
 
     def __init__(self, renderers, canvases, rgb, *, rank, spp_total, my_spp, mode, dist=None, allreduce=None):
@@ -128,8 +136,12 @@ class PipelinedFrames:
                              "be pointed at the legacy null stream (pt_set_stream(NULL) = the context's own stream)")
         # One trace stream per canvas: frames k and k+1 are independent, so the head of
         # frame k+1's kernel fills the CUs that the tail of frame k's kernel leaves idle.
-        self.mains = [torch.cuda.current_stream(), None]
-        self.mains[1], self._spare = stream_on_another_queue(self.mains[0])
+        self.depth = len(renderers)
+        self.mains, self._spare = [torch.cuda.current_stream()], []
+        while len(self.mains) < self.depth:
+            st, spare = stream_on_another_queue(self.mains[0], also=self.mains[1:])
+            self.mains.append(st)
+            self._spare += spare
         # The output stream has the DEFAULT priority, on purpose.  On a high-priority stream (hipStreamCreateWithPriority)
         # this same loop can hang in drain(): reproduced in round 2 with and without a collective, depending only on
         # which streams the process had created before (profiles/r02_priority_probe.txt).  The
@@ -139,16 +151,16 @@ class PipelinedFrames:
         self.side = torch.cuda.Stream()
         for r, m in zip(renderers, self.mains):
             r.set_stream(m.cuda_stream)
-        self.done = [None, None]          # event: canvas k % 2 is free again
+        self.done = [None] * self.depth   # event: canvas k % depth is free again
         self.k = 0
 
     def step(self):
         torch = self.torch
-        b = self.k & 1
+        b = self.k % self.depth
         r, cv, main = self.r[b], self.cv[b], self.mains[b]
         with torch.cuda.stream(main):
             if self.done[b] is not None:
-                main.wait_event(self.done[b])                # frame k-2's output has left this canvas
+                main.wait_event(self.done[b])                # frame k-depth's output has left this canvas
             r.reset()
             r.trace(self.my_spp)
             work = None

@@ -11,7 +11,8 @@ import oracle as O
 pytestmark = pytest.mark.gpu
 
 
-def test_pipelined_frames_equal_inline_frames():
+@pytest.mark.parametrize("depth", [2, 3])
+def test_pipelined_frames_equal_inline_frames(depth):
     import torch
     import pathtracer_amd as pa
     from pathtracer_amd.distributed import PipelinedFrames, canvas_tensor
@@ -27,16 +28,18 @@ def test_pipelined_frames_equal_inline_frames():
 
     stream = torch.cuda.Stream()
     with torch.cuda.stream(stream):
-        rs = [pa.Renderer(P, seed=3) for _ in range(2)]
+        rs = [pa.Renderer(P, seed=3) for _ in range(depth)]      # frames in flight: canvases and trace streams
         cvs = [canvas_tensor(q, 0) for q in rs]
         rgbs = [torch.zeros(H * W * 3, dtype=torch.uint8, device="cuda") for _ in rs]
         pipe = PipelinedFrames(rs, cvs, rgbs, rank=0, spp_total=SPP, my_spp=SPP, mode=pa.PT_RGB8_MEAN_CLAMP, dist=None)
+        assert pipe.depth == depth and len(pipe.mains) == depth
         seen = []
         for k in range(7):
             b = pipe.step()
             if k >= 1:                                     # read frame k-1 while frame k is in flight
-                pipe.done[1 - b].synchronize()
-                seen.append(rgbs[1 - b].cpu().numpy().reshape(W, H, 3).copy())
+                prev = (b - 1) % depth
+                pipe.done[prev].synchronize()
+                seen.append(rgbs[prev].cpu().numpy().reshape(W, H, 3).copy())
         pipe.drain()
         seen.append(rgbs[b].cpu().numpy().reshape(W, H, 3).copy())
         for q in rs:
