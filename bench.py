@@ -289,11 +289,18 @@ def main():
         if collective == "torch":
             nccl_group = dist.new_group(backend="nccl")
 
+    # PT_BENCH_COLLECTIVE_EXTRA_US (experiment, one-GPU boxes): a spin of that many microseconds queued behind the
+    # all-reduce on the same stream -- a world of 1 reduces with a copy that takes no time once it runs, a world of 8
+    # moves 2 x 7/8 x 24.9 MB over xGMI; the line printed says so and is not a measurement
+    extra_us = float(os.environ.get("PT_BENCH_COLLECTIVE_EXTRA_US", "0"))
+
     def allreduce(q, cv):
         if rehearsal:
             return None
         if collective == "libpt":
             q.allreduce_sum()                           # ncclAllReduce on the context's stream, into its total
+            if extra_us > 0:
+                torch.cuda._sleep(int(extra_us * 2400))
             return None
         return dist.all_reduce(cv, op=dist.ReduceOp.SUM, group=nccl_group, async_op=True)
 
@@ -391,7 +398,9 @@ def main():
                        "collective": None if not multi else
                                      (f"libpt ncclAllReduce behind the C ABI (pt_allreduce_sum), {comm.get('n_ranks')} RCCL ranks, "
                                       f"RCCL version code {comm.get('rccl_version')}" if collective == "libpt"
-                                      else "torch.distributed all_reduce (nccl = RCCL)" if collective == "torch" else collective),
+                                      else "torch.distributed all_reduce (nccl = RCCL)" if collective == "torch" else collective)
+                                     + (f" + an artificial {extra_us:g}-us spin behind it (PT_BENCH_COLLECTIVE_EXTRA_US: NOT a measurement)"
+                                        if multi and extra_us > 0 else ""),
                        "value_mode": "wall time of K pipelined frames (barrier + device synchronize on both sides, "
                                      "max over ranks); consecutive frames overlap on two streams"
                                      if pipe is not None else "wall time of K in-line frames",
