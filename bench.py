@@ -102,6 +102,62 @@ def rank_environments(n, port, base=None):
     return envs
 
 
+def visible_devices_from_env(env=None):
+    """How many GPUs the environment lets this process see, or None if it does not say: a launcher may hand each rank
+    its own HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES (CUDA_VISIBLE_DEVICES is honoured by HIP too); device ordinals
+    then count the VISIBLE devices.  An empty value hides every device."""
+    env = os.environ if env is None else env
+    n = None
+    for key in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        if key in env:
+            k = len([x for x in env[key].split(",") if x.strip() != ""])
+            n = k if n is None else min(n, k)
+    return n
+
+
+def device_for_rank(local_rank, n_visible):
+    """The HIP ordinal of a rank's GPU among the devices its process can see: its local rank where the process sees
+    the whole node, ordinal 0 where the launcher gave it exactly one device, round-robin in between."""
+    if n_visible is None or n_visible <= 0:
+        raise RuntimeError("bench.py: no visible GPU for this rank (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES hide them all?)")
+    return local_rank if local_rank < n_visible else local_rank % n_visible
+
+
+def agree_on_libpt_collective(dist, rank, world, make_id, init_rank, own_world_of_one=False):
+    """Set up libpt's RCCL communicator on every rank, or agree -- all ranks together -- that it cannot be done.
+    Every rank executes the SAME sequence of control-plane (gloo) collectives whatever fails where: rank 0's id, or
+    None if it could not be made, is ALWAYS broadcast; every rank then tries to join and the outcome is a MIN
+    all-reduce.  (Round 2 made the id inside the try that also held the broadcast: a failure on rank 0 skipped the
+    broadcast the other ranks were waiting in.)  own_world_of_one: every rank makes an id of its own and a
+    communicator of one rank (the rehearsal on a one-GPU box); the agreement still runs.
+    Returns (ok, reason)."""
+    import torch
+    uid, why = None, ""
+    if own_world_of_one or rank == 0:
+        try:
+            uid = make_id()
+        except Exception as e:                          # noqa: BLE001 (reported, then decided by all ranks together)
+            why = f"rank {rank}: no RCCL id through libpt: {e}"
+    if not own_world_of_one:
+        box = [uid]
+        dist.broadcast_object_list(box, src=0)
+        uid = box[0]
+        if uid is None and not why:
+            why = "rank 0 could not make an RCCL id through libpt"
+    ok = 0
+    if uid is not None:
+        try:
+            init_rank(uid, 0 if own_world_of_one else rank, 1 if own_world_of_one else world)
+            ok = 1
+        except Exception as e:                          # noqa: BLE001
+            why = f"rank {rank}: pt_comm_init_rank: {e}"
+    if why:
+        print("bench.py: libpt collective unavailable: " + why, file=sys.stderr, flush=True)
+    flag = torch.tensor([ok], dtype=torch.int64)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    return int(flag.item()) == 1, why
+
+
 def self_launch(n, argv):
     """`python bench.py --gpus N` typed as is: start the N rank processes (this
     same script with the rank environment), relay rank 0's stdout -- the ONE JSON
@@ -195,9 +251,24 @@ def main():
         dist.init_process_group("gloo")
         t = torch.tensor([rank + 1, local_rank + 1], dtype=torch.int64)
         dist.all_reduce(t)
+        out = {"dry_run": True, "n_gpus": world, "rank_sum": int(t[0]), "local_rank_sum": int(t[1])}
+        # PT_BENCH_DRY_FAIL = "id" | "init<rank>": the libpt-collective agreement with stand-ins that fail there
+        fail_at = os.environ.get("PT_BENCH_DRY_FAIL")
+        if fail_at:
+            def make_id():
+                if fail_at == "id":
+                    raise RuntimeError("forced: no id")
+                return b"x" * 128
+
+            def init_rank(uid, rk, n):
+                if fail_at == f"init{rank}":
+                    raise RuntimeError("forced: init")
+            ok, _ = agree_on_libpt_collective(dist, rank, world, make_id, init_rank)
+            t2 = torch.tensor([1], dtype=torch.int64)
+            dist.all_reduce(t2)                          # the ranks are still in step after the agreement
+            out.update(libpt_collective=ok, in_step=int(t2[0]) == world)
         if rank == 0:
-            print(json.dumps({"dry_run": True, "n_gpus": world, "rank_sum": int(t[0]), "local_rank_sum": int(t[1])}),
-                  file=json_out, flush=True)
+            print(json.dumps(out), file=json_out, flush=True)
         dist.destroy_process_group()
         return
 
@@ -205,14 +276,17 @@ def main():
     import pathtracer_amd as pa
     from pathtracer_amd.distributed import PipelinedFrames, allreduce_canvas, canvas_tensor, shard_samples
 
-    if not torch.cuda.is_available():
+    if torch.cuda.device_count() == 0 or not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: libpt has no CPU path")
-    # PT_BENCH_REHEARSE_ONE_GPU=1: every rank on device 0 and NO collective (RCCL refuses two ranks on one device):
-    # a rehearsal of the N > 1 control flow -- launcher, gloo rendezvous, sample split, fences, max of the time, sum
-    # of the segments -- on a one-GPU box.  The line it prints says so and is not a measurement.
+    # PT_BENCH_REHEARSE_ONE_GPU=1: every rank on device 0, frames NOT combined across ranks (RCCL refuses two ranks of
+    # one communicator on one device): a rehearsal of the N > 1 control flow -- launcher, gloo rendezvous, sample
+    # split, fences, max of the time, sum of the segments -- on a one-GPU box; with --collective libpt every rank runs
+    # libpt's all-reduce over a communicator of its own with one rank, so the collective call sits in the multi-rank
+    # loop.  The line it prints says so and is not a measurement.
     rehearsal = os.environ.get("PT_BENCH_REHEARSE_ONE_GPU") == "1" and world > 1
-    if rehearsal:
-        local_rank = 0
+    # the rank's GPU among the devices this process can see (a launcher may have set HIP_VISIBLE_DEVICES /
+    # ROCR_VISIBLE_DEVICES per rank; torch.cuda.device_count() counts the visible ones without touching a GPU)
+    local_rank = 0 if rehearsal else device_for_rank(local_rank, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dist = None
     # PT_BENCH_FORCE_DIST=1 drives the collective path with a world of 1 (rehearsal on a 1-GPU box)
@@ -265,27 +339,28 @@ def main():
     canvas = canvases[0]
     rgbs = [torch.empty(args.height * args.width * 3, dtype=torch.uint8, device="cuda") for _ in rs]
     rgb = rgbs[0]
-    # The frame's collective.  libpt: one RCCL communicator per context (frames k and k+1 are in flight together
-    # on two streams), rank 0's id handed round over gloo.  If RCCL cannot be reached through libpt on this
-    # machine every rank falls back to torch's all-reduce together, and the JSON line says which one ran.
-    collective, comm = None, {}
+    # The frame's collective.  libpt: ONE RCCL communicator per rank -- the first context joins it with rank 0's id,
+    # handed round over gloo, and the other contexts of the frame pipeline share it (pt_comm_share: frames k and k+1
+    # are in flight on two streams, their all-reduces run in the order they were queued).  If RCCL cannot be
+    # reached through libpt on this machine every rank falls back to torch's all-reduce together, and the JSON
+    # line says which one ran.
+    collective, comm, comm_per_ctx = None, {}, []
     if multi:
-        collective = "none (rehearsal on one GPU: frames are NOT combined)" if rehearsal else args.collective
+        collective = args.collective
+        if rehearsal and collective != "libpt":
+            collective = "none (rehearsal on one GPU: frames are NOT combined)"
         if collective == "libpt":
-            ok = 1
-            try:
-                for q in rs:
-                    box = [pa.Renderer.comm_unique_id() if rank == 0 else None]
-                    dist.broadcast_object_list(box, src=0)
-                    q.comm_init_rank(box[0], rank, world)
-                comm = rs[0].comm_info()
-            except Exception as e:                      # noqa: BLE001 (reported, then decided by all ranks together)
-                print(f"bench.py: rank {rank}: libpt collective unavailable: {e}", file=sys.stderr)
-                ok = 0
-            flag = torch.tensor([ok], dtype=torch.int64)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if int(flag.item()) == 0:
-                collective = "torch"
+            def init_rank(uid, rk, n):
+                rs[0].comm_init_rank(uid, rk, n)
+                for q in rs[1:]:
+                    q.comm_share(rs[0])
+            ok, _ = agree_on_libpt_collective(dist, rank, world, pa.Renderer.comm_unique_id, init_rank,
+                                              own_world_of_one=rehearsal)
+            if ok:
+                comm_per_ctx = [q.comm_info() for q in rs]
+                comm = comm_per_ctx[0]
+            else:
+                collective = "none (rehearsal on one GPU: frames are NOT combined)" if rehearsal else "torch"
         if collective == "torch":
             nccl_group = dist.new_group(backend="nccl")
 
@@ -295,13 +370,13 @@ def main():
     extra_us = float(os.environ.get("PT_BENCH_COLLECTIVE_EXTRA_US", "0"))
 
     def allreduce(q, cv):
-        if rehearsal:
-            return None
         if collective == "libpt":
             q.allreduce_sum()                           # ncclAllReduce on the context's stream, into its total
             if extra_us > 0:
                 torch.cuda._sleep(int(extra_us * 2400))
             return None
+        if collective != "torch":
+            return None                                 # (rehearsal without a collective)
         return dist.all_reduce(cv, op=dist.ReduceOp.SUM, group=nccl_group, async_op=True)
 
     pipe = PipelinedFrames(rs, canvases, rgbs, rank=rank, spp_total=args.spp, my_spp=my_spp,
@@ -352,8 +427,32 @@ def main():
     fence()
     kern_ms = sum(ev) / len(ev) / max(launches, 1)
 
+    # N > 1: the collective on its own, event-timed on the launch stream, every rank entering together (a barrier
+    # first, so the figure is the all-reduce and not the wait for the slowest rank's trace)
+    coll_ms = []
+    if multi and collective in ("libpt", "torch"):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        r_stream = pipe.mains[rs.index(r)] if pipe is not None else stream     # the stream context r launches on
+        for _ in range(4):
+            fence()
+            with torch.cuda.stream(r_stream):
+                e0.record(r_stream)
+                work = allreduce(r, canvases[rs.index(r)])
+                if work is not None:
+                    work.wait()
+                e1.record(r_stream)
+            e1.synchronize()
+            coll_ms.append(e0.elapsed_time(e1))
+        coll_ms = coll_ms[1:]                           # the first one may set up RCCL's channels
+
     t_el = torch.tensor([elapsed], dtype=torch.float64)
+    rank_ms = [elapsed / args.steps * 1e3]
     if dist is not None:
+        mine = torch.tensor([elapsed / args.steps * 1e3, sum(coll_ms) / len(coll_ms) if coll_ms else 0.0], dtype=torch.float64)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        rank_ms = [float(x[0]) for x in every]
+        rank_coll_ms = [float(x[1]) for x in every]
         dist.all_reduce(t_el, op=dist.ReduceOp.MAX)
         dist.all_reduce(segs_step, op=dist.ReduceOp.SUM)
     elapsed = float(t_el.item())
@@ -395,12 +494,26 @@ def main():
                                        else "general",
                        "scene_kernel_compiler": r.jit_info() if specialised else None,
                        "parallelism": f"sample-split x{world}",
+                       "device_ordinal_rank0": local_rank,
+                       "visible_devices": torch.cuda.device_count(),
                        "collective": None if not multi else
                                      (f"libpt ncclAllReduce behind the C ABI (pt_allreduce_sum), {comm.get('n_ranks')} RCCL ranks, "
-                                      f"RCCL version code {comm.get('rccl_version')}" if collective == "libpt"
+                                      f"RCCL version code {comm.get('rccl_version')}, one communicator per rank shared by its "
+                                      f"{len(rs)} context(s) (pt_comm_share)"
+                                      + ("; REHEARSAL on one GPU: a communicator of ONE rank per rank process, frames are NOT combined"
+                                         if rehearsal else "") if collective == "libpt"
                                       else "torch.distributed all_reduce (nccl = RCCL)" if collective == "torch" else collective)
                                      + (f" + an artificial {extra_us:g}-us spin behind it (PT_BENCH_COLLECTIVE_EXTRA_US: NOT a measurement)"
                                         if multi and extra_us > 0 else ""),
+                       "comm_info_per_context": comm_per_ctx if multi else None,
+                       "per_rank_ms_per_step": None if dist is None else
+                                               {"min": round(min(rank_ms), 4), "max": round(max(rank_ms), 4),
+                                                "all": [round(x, 4) for x in rank_ms]},
+                       "collective_ms": None if not coll_ms else
+                                        {"rank0_mean": round(sum(coll_ms) / len(coll_ms), 4), "rank0_min": round(min(coll_ms), 4),
+                                         "per_rank_mean": [round(x, 4) for x in rank_coll_ms],
+                                         "how": "the all-reduce alone after a barrier, HIP events on the launch stream, "
+                                                "3 repetitions after one untimed; not part of the timed steps"},
                        "value_mode": "wall time of K pipelined frames (barrier + device synchronize on both sides, "
                                      "max over ranks); consecutive frames overlap on two streams"
                                      if pipe is not None else "wall time of K in-line frames",

@@ -188,15 +188,17 @@ int pt_read_rgb8(pt_ctx *ctx, uint8_t *out, int32_t mode);
 /* pt_read_rgb8 for callers that cannot allocate.  No counterpart in the
  * reference; it is for hosts that may not call hipMalloc where they read a frame:
  * a tight serving loop (one pt_trace(1) + one read per client message, the
- * pull-next-frame contract of app/Web.hs:42-65), code under HIP graph capture,
- * harnesses that forbid allocation.  pt_read_rgb8 stages the quantised image in a
+ * pull-next-frame contract of app/Web.hs:42-65), harnesses that forbid
+ * allocation.  (Not for HIP graph capture: like pt_read_rgb8 it copies to the
+ * caller's host buffer and synchronises the stream.)  pt_read_rgb8 stages the quantised image in a
  * device buffer it allocates on first use; this variant stages it in a static
  * device array of 8 MiB that every GPU the library runs on holds until the
  * process ends, and calls no hipMalloc / hipFree or allocating library routine.
  * Same output, byte for byte.  Images above 8,388,608 bytes (H*W*3; 1920x1080
  * fits) are refused with PT_ERR_LIMIT.  All contexts on one GPU share that GPU's
- * array: calls that overlap in time on one GPU (two contexts, two threads) race
- * -- serialise them. */
+ * array; the call holds a per-GPU lock from the kernel that fills it to the end
+ * of the copy out of it, so calls from several contexts or threads on one GPU
+ * take turns (each context still from one thread at a time, as everywhere). */
 int pt_read_rgb8_noalloc(pt_ctx *ctx, uint8_t *out, int32_t mode);
 
 /* Parity hook for rayFromCamToPixel + closestObjectTo on the primary ray
@@ -335,6 +337,15 @@ int pt_create_multi(pt_ctx **out, const pt_params *params, const int32_t *device
 int pt_comm_unique_id(void *id);
 int pt_comm_init_rank(pt_ctx *ctx, const void *id, int32_t rank, int32_t n_ranks);
 int pt_allreduce_sum(pt_ctx *ctx);
+/* A second context of the same rank, on the same device and of the same canvas
+ * size (frames in flight: frame k+1 is traced into one canvas while frame k's
+ * all-reduce runs on another), uses `owner`'s communicator instead of creating
+ * one of its own: one set of RCCL channels and proxy threads per rank, one
+ * collective initialisation.  RCCL runs the all-reduces of one communicator in
+ * the order they were queued; every rank must queue them in the same order over
+ * all the contexts that share it.  The communicator lives until the last
+ * context using it is destroyed.  No counterpart in the reference. */
+int pt_comm_share(pt_ctx *ctx, pt_ctx *owner);
 /* What a context's collective runs over: RCCL ranks, this context's rank, the
  * devices driven from this process, and RCCL's version code (0: no
  * communicator -- an ordinary single-GPU context).  Any pointer may be NULL. */

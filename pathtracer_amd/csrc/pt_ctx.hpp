@@ -6,6 +6,7 @@
 #include "../../include/pt.h"
 #include "pt_internal.hpp"
 
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -45,7 +46,8 @@ struct pt_ctx {
     // ---- multi-GPU (pt_multi.hip) ----
     pt_group *group = nullptr;         // non-null: the head of a single-process device group (pt_create_multi);
                                        // a head owns no device memory of its own
-    void *comm = nullptr;              // ncclComm_t of a process-per-GPU context (pt_comm_init_rank)
+    void *comm = nullptr;              // ncclComm_t of a process-per-GPU context (pt_comm_init_rank, pt_comm_share)
+    std::shared_ptr<void> comm_ref;    // owns it: the communicator is destroyed when the last context that uses it lets go
     int comm_rank = 0, comm_size = 1;
     float *d_total = nullptr;          // the all-reduced canvas (the context's own canvas stays its partial sum)
     bool total_valid = false;          // d_total holds the sum over all ranks of the current canvases

@@ -113,6 +113,8 @@ struct pt_group {
     int64_t samples_done = 0;
     bool total_valid = false;
     bool timing = false;
+    bool failed = false;                        // a member's trace failed after others had added their blocks: the
+                                                // members' sample counts disagree until pt_reset
 };
 
 namespace pt {
@@ -146,6 +148,9 @@ int group_trace(pt_ctx *head, int32_t iters)
 {
     pt_group *g = head->group;
     if (iters < 0) return fail(head, PT_ERR_INVALID, "pt_trace: iters < 0");
+    if (g->failed)
+        return fail(head, PT_ERR_INVALID, "pt_trace: an earlier pt_trace of this device group failed part-way (some members "
+                                          "had added their blocks); pt_reset before tracing again");
     if ((int64_t)head->p.sample_offset + (g->samples_done + iters) * (int64_t)head->p.sample_stride >= MAX_GLOBAL_SAMPLES)
         return fail(head, PT_ERR_LIMIT, "pt_trace: global sample index would exceed 2^26");
     const int n = (int)g->members.size();
@@ -159,7 +164,11 @@ int group_trace(pt_ctx *head, int32_t iters)
             if (!m->have_scene) return fail(head, PT_ERR_NO_SCENE, "pt_trace: no scene uploaded");
             continue;
         }
-        if (int s = up(head, m, trace_block(m, k, cnt))) return s;
+        if (int s = up(head, m, trace_block(m, k, cnt))) {
+            // members 0..i-1 hold this call's blocks already: a retry would count those samples twice
+            if (k != g->samples_done) g->failed = true;
+            return s;
+        }
         k += cnt;
     }
     g->samples_done += iters;
@@ -172,6 +181,7 @@ int group_reset(pt_ctx *head)
         if (int s = up(head, m, pt_reset(m))) return s;
     head->group->samples_done = 0;
     head->group->total_valid = false;
+    head->group->failed = false;
     return PT_OK;
 }
 
@@ -181,6 +191,8 @@ int group_total(pt_ctx *head, pt_ctx **leader)
 {
     pt_group *g = head->group;
     *leader = g->members[g->on_dev[0][0]];
+    if (g->failed)
+        return fail(head, PT_ERR_INVALID, "read: a pt_trace of this device group failed part-way; pt_reset first");
     if (g->total_valid) return PT_OK;
     const size_t count = npix(head) * 3;
     std::vector<const float *> send(g->devices.size());
@@ -263,6 +275,7 @@ int group_write_sum_f32(pt_ctx *head, const float *in, int64_t samples_done)
     }
     g->samples_done = samples_done;
     g->total_valid = false;
+    g->failed = false;
     return PT_OK;
 }
 
@@ -305,7 +318,8 @@ void group_destroy(pt_ctx *head)
 
 void comm_destroy(pt_ctx *c)
 {
-    if (c->comm) { (void)rccl().comm_destroy((ncclComm_t)c->comm); c->comm = nullptr; }
+    c->comm = nullptr;
+    c->comm_ref.reset();               // ncclCommDestroy when this was the last context using it
     if (c->d_total) { (void)hipFree(c->d_total); c->d_total = nullptr; }
     c->total_valid = false;
 }
@@ -392,6 +406,23 @@ int pt_comm_init_rank(pt_ctx *c, const void *id, int32_t rank, int32_t n_ranks)
     ncclComm_t comm = nullptr;
     PT_NCCL(c, r.comm_init_rank(&comm, n_ranks, uid, rank));
     c->comm = comm; c->comm_rank = rank; c->comm_size = n_ranks;
+    c->comm_ref = std::shared_ptr<void>(comm, [](void *cm) { if (cm) (void)rccl().comm_destroy((ncclComm_t)cm); });
+    return PT_OK;
+}
+
+int pt_comm_share(pt_ctx *c, pt_ctx *owner)
+{
+    if (int s = check_ctx(c)) return s;
+    if (!owner || owner == c) return fail(c, PT_ERR_INVALID, "pt_comm_share: need another context");
+    if (c->group || owner->group) return fail(c, PT_ERR_INVALID, "pt_comm_share: not for pt_create_multi contexts");
+    if (!owner->comm) return fail(c, PT_ERR_INVALID, "pt_comm_share: the other context has no communicator (pt_comm_init_rank first)");
+    if (c->comm) return fail(c, PT_ERR_INVALID, "pt_comm_share: the context has a communicator already");
+    if (c->p.device != owner->p.device) return fail(c, PT_ERR_INVALID, "pt_comm_share: the contexts are on different devices");
+    if (c->p.height != owner->p.height || c->p.width != owner->p.width)
+        return fail(c, PT_ERR_INVALID, "pt_comm_share: the contexts' canvases differ in size");
+    if (!c->d_total) PT_HIP(c, hipMalloc((void **)&c->d_total, npix(c) * 3 * sizeof(float)));
+    c->comm = owner->comm; c->comm_ref = owner->comm_ref;
+    c->comm_rank = owner->comm_rank; c->comm_size = owner->comm_size;
     return PT_OK;
 }
 

@@ -1,8 +1,9 @@
 // pt_noalloc.hip -- pt_read_rgb8_noalloc: the one entry point of libpt that
 // allocates nothing (include/pt.h), for callers that cannot call hipMalloc:
 // tight serving loops (the pull-next-frame loop of app/Web.hs:42-65 answers a
-// client message with one pt_trace(1) + one RGB8 read), code under HIP graph
-// capture, harnesses that forbid allocation.
+// client message with one pt_trace(1) + one RGB8 read), harnesses that forbid
+// allocation.  (Not for HIP graph capture: the call ends with a copy to the
+// caller's pageable buffer and a stream synchronisation, which capture forbids.)
 //
 // pt_read_rgb8 stages the quantised image in a device buffer it allocates on
 // first use (pt_ctx::d_rgb).  Here that staging buffer is a file-scope device
@@ -23,8 +24,12 @@ constexpr size_t SCRATCH_BYTES = (size_t)8 << 20;          // 8 MiB: RGB8 of up 
 static __device__ __align__(256) unsigned char scratch[SCRATCH_BYTES];
 
 constexpr int MAX_DEVICES = 64;
-std::mutex g_mu;
+std::mutex g_mu;                                           // guards g_scratch
 unsigned char *g_scratch[MAX_DEVICES];                     // per device: the address of ITS copy of `scratch`
+// One device's array is shared by every context on that device: a call holds the device's mutex from the kernel
+// that fills the array until the copy out of it has completed, so calls from several contexts or threads on one
+// GPU queue up instead of overwriting each other's image (the call is synchronous anyway).
+std::mutex g_busy[MAX_DEVICES];
 
 } // namespace
 
@@ -65,8 +70,11 @@ extern "C" int pt_read_rgb8_noalloc(pt_ctx *c, uint8_t *out, int32_t mode)
         ptr = g_scratch[device];
     }
     if (!ptr) return fail(c, PT_ERR_UNSUPPORTED, "pt_read_rgb8_noalloc: no static scratch on this device (ordinal beyond 63)");
+    std::lock_guard<std::mutex> busy(g_busy[device]);
     if (int s = rgb8_from(c, src, ptr, mode, mean_samples(c, 0), on->stream)) return s;
-    PT_HIP(c, hipMemcpyAsync(out, ptr, bytes, hipMemcpyDeviceToHost, on->stream));
-    PT_HIP(c, hipStreamSynchronize(on->stream));
+    const hipError_t ec = hipMemcpyAsync(out, ptr, bytes, hipMemcpyDeviceToHost, on->stream);
+    const hipError_t es = hipStreamSynchronize(on->stream);            // also after a failed copy: the kernel must be done with the array
+    PT_HIP(c, ec);
+    PT_HIP(c, es);
     return PT_OK;
 }

@@ -162,6 +162,10 @@ class Renderer:
             raise ValueError("comm_init_rank: the id is PT_COMM_ID_BYTES bytes")
         check(lib.pt_comm_init_rank(self._ctx, C.c_char_p(uid), rank, n_ranks), self._ctx)
 
+    def comm_share(self, owner: "Renderer"):
+        """pt_comm_share: use `owner`'s RCCL communicator (a second canvas of the same rank, frames in flight)."""
+        check(lib.pt_comm_share(self._ctx, owner._ctx), self._ctx)
+
     def allreduce_sum(self):
         """One ncclAllReduce(sum) of the canvas over all ranks, queued on the context's stream; the reads
         return the total until the next trace / reset."""

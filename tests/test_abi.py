@@ -79,6 +79,7 @@ def test_argument_validation_needs_no_gpu():
     assert _lib.lib.pt_comm_unique_id(None) == _lib.PT_ERR_INVALID
     assert _lib.lib.pt_allreduce_sum(None) == _lib.PT_ERR_INVALID
     assert _lib.lib.pt_comm_init_rank(None, None, 0, 1) == _lib.PT_ERR_INVALID
+    assert _lib.lib.pt_comm_share(None, None) == _lib.PT_ERR_INVALID
 
 
 def test_product_never_touches_the_oracle():

@@ -1,7 +1,7 @@
 """bench.py itself on the GPU box: the one-GPU line, and the N > 1 control flow rehearsed with every rank on device 0
 (PT_BENCH_REHEARSE_ONE_GPU=1: self-launched ranks, gloo rendezvous, sample split, fences, max of the time, sum of the
-segments; no collective, because RCCL refuses two ranks on one device -- the collectives themselves are tested with
-worlds of 1 in tests/test_gpu_multi.py)."""
+segments; libpt's ncclAllReduce runs in that loop over a communicator of ONE rank per rank process, because RCCL
+refuses two ranks of one communicator on one device)."""
 import json
 import os
 import subprocess
@@ -34,8 +34,17 @@ def test_one_gpu_line_and_two_rank_rehearsal():
         assert key in one["roofline"]
     assert "value_mode" in one["config"] and "scene_kernel_compiler" in one["config"]
 
-    two = _bench(["--gpus", "2"] + SMALL, {"PT_BENCH_REHEARSE_ONE_GPU": "1"})
-    assert two["n_gpus"] == 2 and "rehearsal" in two["config"]["collective"]
+    two = _bench(["--gpus", "2", "--collective", "libpt"] + SMALL, {"PT_BENCH_REHEARSE_ONE_GPU": "1"})
+    cfg = two["config"]
+    assert two["n_gpus"] == 2 and "REHEARSAL" in cfg["collective"] and "libpt ncclAllReduce" in cfg["collective"]
+    # libpt's collective sat in the two-rank loop: one communicator (of one rank, on this one-GPU box) per rank
+    # process, shared by the rank's two pipelined contexts
+    assert len(cfg["comm_info_per_context"]) == 2
+    assert all(ci["n_ranks"] == 1 and ci["rccl_version"] > 0 for ci in cfg["comm_info_per_context"])
+    assert len(cfg["per_rank_ms_per_step"]["all"]) == 2
+    assert cfg["per_rank_ms_per_step"]["min"] <= cfg["per_rank_ms_per_step"]["max"]
+    assert abs(cfg["per_rank_ms_per_step"]["max"] - two["ms_per_step"]) < 1e-3        # value is timed on the slowest rank
+    assert cfg["collective_ms"]["rank0_mean"] > 0 and len(cfg["collective_ms"]["per_rank_mean"]) == 2
     # two ranks of 32 samples each trace the frame's 64: the same paths as one rank (Philox is keyed by the global
     # sample index), plus one more per-pixel primary search for the second rank's context
     assert two["config"]["paths_per_step"] == one["config"]["paths_per_step"]

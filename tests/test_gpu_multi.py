@@ -159,3 +159,34 @@ def test_allreduce_needs_a_communicator():
     with pa.Renderer(pa.Params(32, 32, 500.0, 1, 4)) as r:
         with pytest.raises(pa.PtError):
             r.allreduce_sum()
+
+
+def test_contexts_of_a_rank_share_one_communicator():
+    """pt_comm_share: the second canvas of a rank's frame pipeline uses the first's communicator (world of 1 here);
+    both reduce correctly, in either order, and the communicator outlives the context that created it."""
+    import pathtracer_amd as pa
+    want8, _, _, _ = plain(8)
+    want5, _, _, _ = plain(5)
+    a = pa.Renderer(pa.Params(H, W, 500.0, 8, B), seed=5)
+    b = pa.Renderer(pa.Params(H, W, 500.0, 8, B), seed=5)
+    c = pa.Renderer(pa.Params(H, W + 8, 500.0, 8, B), seed=5)
+    try:
+        with pytest.raises(pa.PtError):
+            b.comm_share(a)                             # a has no communicator yet
+        a.comm_init_rank(pa.Renderer.comm_unique_id(), 0, 1)
+        b.comm_share(a)
+        assert b.comm_info() == a.comm_info() and b.comm_info()["rccl_version"] > 0
+        with pytest.raises(pa.PtError):
+            b.comm_share(a)                             # one communicator per context
+        with pytest.raises(pa.PtError):
+            c.comm_share(a)                             # another canvas size
+        a.trace(8); b.trace(5)
+        b.allreduce_sum(); a.allreduce_sum()
+        assert np.array_equal(a.read_sum_f32(), want8)
+        assert np.array_equal(b.read_sum_f32(), want5)
+        a.close()                                       # b keeps the communicator alive
+        b.trace(3)
+        b.allreduce_sum()
+        np.testing.assert_allclose(b.read_sum_f32(), want8, rtol=4e-6, atol=1e-6)
+    finally:
+        a.close(); b.close(); c.close()

@@ -39,3 +39,53 @@ def test_noalloc_read_of_a_device_group():
     with pa.Renderer(pa.Params(96, 64, 500.0, 6, 6), seed=4, devices=[0, 0]) as g:
         g.trace(6)
         assert np.array_equal(g.read_rgb8_noalloc(pa.PT_RGB8_MEAN_CLAMP), g.read_rgb8(pa.PT_RGB8_MEAN_CLAMP))
+
+
+def _free_bytes():
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so.7")                                  # the runtime libpt.so is linked against
+    free, total = C.c_size_t(), C.c_size_t()
+    assert hip.hipMemGetInfo(C.byref(free), C.byref(total)) == 0
+    return free.value
+
+
+def test_noalloc_read_leaves_the_free_device_memory_unchanged():
+    """hipMemGetInfo's free bytes before and after the call are equal (the first call of a process may load the
+    kernel's code object, so one call warms up); pt_read_rgb8 on a fresh context, by contrast, allocates."""
+    import pathtracer_amd as pa
+    with pa.Renderer(pa.Params(640, 480, 500.0, 2, 4), seed=3) as r:
+        r.trace(2)
+        r.read_rgb8_noalloc()
+        r.synchronize()
+        before = _free_bytes()
+        for mode in (pa.PT_RGB8_REFERENCE, pa.PT_RGB8_MEAN_GAMMA):
+            got = r.read_rgb8_noalloc(mode)
+            assert _free_bytes() == before, mode
+        want = r.read_rgb8(pa.PT_RGB8_MEAN_GAMMA)                     # allocates its staging buffer on first use
+        assert np.array_equal(got, want)
+        assert _free_bytes() <= before
+
+
+def test_noalloc_reads_of_two_contexts_on_one_device_take_turns():
+    """Two contexts on one GPU share that GPU's static array; reads from two threads must each return their own
+    image (the call holds a per-GPU lock until its copy out of the array has completed)."""
+    import threading
+    import pathtracer_amd as pa
+    a = pa.Renderer(pa.Params(512, 384, 500.0, 3, 6), seed=5)
+    b = pa.Renderer(pa.Params(512, 384, 500.0, 3, 6), seed=6)
+    try:
+        a.trace(3); b.trace(3)
+        want = {id(a): a.read_rgb8(), id(b): b.read_rgb8()}
+        assert not np.array_equal(want[id(a)], want[id(b)])
+        bad = []
+
+        def reader(r):
+            for _ in range(40):
+                if not np.array_equal(r.read_rgb8_noalloc(), want[id(r)]):
+                    bad.append(id(r))
+        ts = [threading.Thread(target=reader, args=(r,)) for r in (a, b)]
+        for t in ts: t.start()
+        for t in ts: t.join()
+        assert not bad
+    finally:
+        a.close(); b.close()
