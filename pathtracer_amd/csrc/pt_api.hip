@@ -244,6 +244,7 @@ void pt_destroy(pt_ctx *c)
     if (c->d_rect) (void)hipFree(c->d_rect);
     if (c->d_partial) (void)hipFree(c->d_partial);
     if (c->d_pix) (void)hipFree(c->d_pix);
+    if (c->d_tile_ctr) (void)hipFree(c->d_tile_ctr);
     if (c->d_bvh_nodes) (void)hipFree(c->d_bvh_nodes);
     if (c->d_bvh_prims) (void)hipFree(c->d_bvh_prims);
     if (c->d_bvh_geom) (void)hipFree(c->d_bvh_geom);
@@ -419,11 +420,18 @@ int pt::trace_block(pt_ctx *c, int64_t k_begin, int32_t iters)
             c->d_partial = nullptr;
         }
     const bool static_path = c->n_obj <= MAX_STATIC_OBJECTS && reuse && !(c->p.flags & PT_FLAG_NO_STEAL);
-    if (static_path && !c->d_pix)
-        if (hipMalloc((void **)&c->d_pix, npix(c) * 2 * sizeof(float4)) != hipSuccess) {
-            (void)hipGetLastError();                 // no memory: every launch repeats the primary pass
+    if (static_path && !c->d_pix) {                  // the kept primary hits, 32 B per pixel (primary_fill_kernel)
+        const hipError_t e = hipMalloc((void **)&c->d_pix, npix(c) * 2 * sizeof(float4));
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
             c->d_pix = nullptr;
+            return fail(c, PT_ERR_HIP, std::string("pt_trace: hipMalloc(primary hits): ") + hipGetErrorString(e));
         }
+    }
+    if (static_path && !c->d_tile_ctr) {
+        PT_HIP(c, hipMalloc((void **)&c->d_tile_ctr, MAX_SLICES * TILE_CTR_STRIDE * sizeof(unsigned int)));
+        PT_HIP(c, hipMemsetAsync(c->d_tile_ctr, 0, MAX_SLICES * TILE_CTR_STRIDE * sizeof(unsigned int), c->stream));
+    }
     if (c->timing) PT_HIP(c, hipEventRecord(c->ev0, c->stream));
     int launches = 0;
     int32_t left = iters;
@@ -439,10 +447,11 @@ int pt::trace_block(pt_ctx *c, int64_t k_begin, int32_t iters)
         a.n_samples = n;
         a.partial = c->d_partial;
         a.pix = static_path ? c->d_pix : nullptr; a.pix_valid = a.pix && c->pix_valid ? 1 : 0;
+        a.tile_ctr = static_path ? c->d_tile_ctr : nullptr;
         PT_HIP(c, launch_trace(a, c->h_geom.data(), reuse, c->has_specular,
                                (c->p.flags & PT_FLAG_LDS_TILES) != 0,
                                (c->p.flags & PT_FLAG_NO_STEAL) == 0, c->stream,
-                               static_path ? c->scene_kernel : nullptr));
+                               static_path ? c->scene_kernel : nullptr, c->tile_base));
         if (a.pix) c->pix_valid = true;              // later launches on this stream read what this one stored
         c->canvas_stale = false;
         c->samples_done += n;

@@ -942,6 +942,23 @@ __global__ __launch_bounds__(BVH_BLOCK) void trace_bvh_kernel(TraceArgs a)
 }
 
 
+// The primary segment of every pixel for trace_static_kernel: fp64, the reference's operation order (primary_hit_f64,
+// the function the parity hook pt_primary_hits runs), once per camera and scene -- the first launch after
+// pt_scene_upload -- kept in a.pix as (P0, d0.x) (d0.yz, record offset 16*(idx+1), -).  The searches are counted.
+__global__ __launch_bounds__(256) void primary_fill_kernel(TraceArgs a)
+{
+    const int npix = a.height * a.width;
+    const int pc = blockIdx.x * 256 + threadIdx.x;
+    if (pc < npix) {
+        const int pi = pc / a.width, pj = pc - pi * a.width;
+        const PrimaryHit ph = primary_hit(a, pi, pj);
+        a.pix[2 * (size_t)pc] = make_float4((float)(ph.t * ph.dx), (float)(ph.t * ph.dy), (float)(ph.t * ph.dz), (float)ph.dx);
+        a.pix[2 * (size_t)pc + 1] = make_float4((float)ph.dy, (float)ph.dz, __int_as_float(16 * (ph.idx + 1)), 0.f);
+    }
+    const unsigned long long n = __builtin_popcountll(__ballot(pc < npix));
+    if ((threadIdx.x & 63) == 0 && n) atomicAdd(seg_lane(a.segments), n);
+}
+
 // canvas += plane 0 + plane 1 + ... (in this order): the sample slices of one launch
 __global__ __launch_bounds__(256) void slice_sum_kernel(float4 *__restrict__ canvas, const float4 *__restrict__ partial,
                                                         size_t n4, int planes)
@@ -958,7 +975,7 @@ __global__ __launch_bounds__(256) void slice_sum_kernel(float4 *__restrict__ can
 
 template <int NS>
 static hipError_t launch_trace_ns(TraceArgs a, const float4 *geom_host, bool reuse, bool spec, bool steal,
-                                  hipStream_t s, hipFunction_t scene_kernel = nullptr)
+                                  hipStream_t s, hipFunction_t scene_kernel = nullptr, unsigned int *tile_base = nullptr)
 {
     // pad the by-value object list to NS with records that never pass the
     // 0 < t < Inf guard (n = 0 gives t = NaN)
@@ -991,8 +1008,22 @@ static hipError_t launch_trace_ns(TraceArgs a, const float4 *geom_host, bool reu
                 a.n_slices = 2;
                 a.slice_n[1] = n / 16; a.slice_n[0] = n - a.slice_n[1]; a.slice_j0[1] = a.slice_n[0];
             }
-            const dim3 sgrid((npix + STATIC_BLOCK - 1) / STATIC_BLOCK, a.n_slices), sblock(STATIC_BLOCK);
+            // PT_PERSIST=<workgroups> (experiment): keep the grid at that many one-wave workgroups per slice; each
+            // walks the tiles blockIdx.x, blockIdx.x + gridDim.x, ... (8192 = the waves the chip holds at 8 per SIMD)
+            static const unsigned persist = getenv("PT_PERSIST") ? (unsigned)atoi(getenv("PT_PERSIST")) : 0u;
+            unsigned gx = (unsigned)((npix + STATIC_BLOCK - 1) / STATIC_BLOCK);
+            const unsigned n_tiles = gx;
+            if (persist && a.tile_ctr && tile_base && gx > persist) gx = persist;
+            if (gx < n_tiles)                                  // persistent: every slice's counter advances by its tiles
+                for (int y = 0; y < a.n_slices; ++y) { a.tile_base[y] = tile_base[y]; tile_base[y] += n_tiles; }
+            const dim3 sgrid(gx, a.n_slices), sblock(STATIC_BLOCK);
             hipError_t e;
+            if (!a.pix) return hipErrorInvalidValue;           // (trace_block allocates it or fails)
+            if (!a.pix_valid) {                                // first launch of this camera and scene: the fp64 primary pass
+                hipLaunchKernelGGL(primary_fill_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, a);
+                if ((e = hipGetLastError()) != hipSuccess) return e;
+                a.pix_valid = 1;
+            }
             // PT_EXTRA_LDS=<bytes>: unused dynamic LDS per workgroup, to lower the waves per SIMD for an occupancy
             // experiment (160 KB per CU: 10240 -> 4 waves per SIMD, 20480 -> 2)
             static const unsigned extra_lds = getenv("PT_EXTRA_LDS") ? (unsigned)atoi(getenv("PT_EXTRA_LDS")) : 0u;
@@ -1056,11 +1087,11 @@ static hipError_t launch_trace_ns(TraceArgs a, const float4 *geom_host, bool reu
 }
 
 hipError_t launch_trace(const TraceArgs &a, const float4 *geom_host, bool reuse, bool spec, bool lds_tiles,
-                        bool steal, hipStream_t s, hipFunction_t scene_kernel)
+                        bool steal, hipStream_t s, hipFunction_t scene_kernel, unsigned int *tile_base)
 {
-    if (a.n_obj <= 4) return launch_trace_ns<4>(a, geom_host, reuse, spec, steal, s, scene_kernel);
+    if (a.n_obj <= 4) return launch_trace_ns<4>(a, geom_host, reuse, spec, steal, s, scene_kernel, tile_base);
     if (a.n_obj <= MAX_STATIC_OBJECTS)
-        return launch_trace_ns<MAX_STATIC_OBJECTS>(a, geom_host, reuse, spec, steal, s, scene_kernel);
+        return launch_trace_ns<MAX_STATIC_OBJECTS>(a, geom_host, reuse, spec, steal, s, scene_kernel, tile_base);
     if (lds_tiles) return launch_trace_ns<-1>(a, geom_host, reuse, spec, false, s);
     if (a.n_nodes > 0) return launch_trace_ns<-2>(a, geom_host, reuse, spec, steal, s);
     return launch_trace_ns<0>(a, geom_host, reuse, spec, steal, s);

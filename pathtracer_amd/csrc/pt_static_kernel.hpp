@@ -145,6 +145,28 @@ __device__ __forceinline__ void take_under(unsigned long long mask, int &bestp, 
         : [m] "s"(mask), [off] "n"(OFF), [key] "v"(key));
 }
 
+// g <- ds_add_rtn_u32(LDS[addr + OFF], val) in the lanes of `mask` (the others keep g); waits for the result
+template <int OFF>
+__device__ __forceinline__ uint32_t lds_add_rtn_under(unsigned long long mask, uint32_t addr, uint32_t val, uint32_t g)
+{
+    unsigned long long saved;
+    asm volatile("s_and_saveexec_b64 %[sv], %[m]\n\t"
+                 "ds_add_rtn_u32 %[g], %[a], %[v] offset:%[off]\n\t"
+                 "s_waitcnt lgkmcnt(0)\n\t"
+                 "s_mov_b64 exec, %[sv]"
+                 : [g] "+v"(g), [sv] "=&s"(saved)
+                 : [m] "s"(mask), [a] "v"(addr), [v] "v"(val), [off] "n"(OFF) : "memory");
+    return g;
+}
+__device__ __forceinline__ uint32_t lds_read_u32(uint32_t addr)
+{
+    return *reinterpret_cast<const volatile __attribute__((address_space(3))) uint32_t *>((uintptr_t)addr);
+}
+__device__ __forceinline__ void lds_write_u32(uint32_t addr, uint32_t x)
+{
+    *reinterpret_cast<volatile __attribute__((address_space(3))) uint32_t *>((uintptr_t)addr) = x;
+}
+
 template <int NS, bool SPH, bool MASKS>
 __device__ __forceinline__ void closest_static(const StaticGeom<NS> &sg, const float4 *__restrict__ rect, f3 o, f3 v, int lastp,
                                                const unsigned long long *excl, unsigned long long *okm,
@@ -254,13 +276,21 @@ __global__ __launch_bounds__(STATIC_BLOCK) void trace_static_kernel(TraceArgs a,
     static_assert(NS > 0, "object list by value");
     constexpr int BLOCK = STATIC_BLOCK;
     constexpr int R = NS + 1;                       // material records per field: miss + NS objects
+    // lane masks of "the primary object is k" and "the last-struck object is k" (closest_static, MASKS)
+#ifdef PT_JIT
+    constexpr bool MASKS = true;      // (8 objects too: their geometry is in the code, not in 64 SGPRs, so the masks fit)
+#else
+    constexpr bool MASKS = NS <= 4;
+#endif
+    // Per pixel of the wave, one record: (P0, record offset), (colour0, e0), (d0, -) and, MASKS, the sharing phase's
+    // state in the same record -- the next global sample index not started in [2].w, the radiance handed over by
+    // helpers in [3].xyz -- so that ONE per-lane LDS address (raddr) names everything of the pixel a lane works on.
+    constexpr int RV = MASKS ? 4 : 3;
     __shared__ float4   s_mat[4 * R];               // field f of object k at [f*R + k + 1]; [f*R] = miss
-    __shared__ uint32_t s_next[BLOCK];              // per pixel: next global sample index not started
-    __shared__ float4   s_pix[BLOCK * 3];           // per pixel: (P0, record offset), (colour0, e0), (d0, -)
-    __shared__ float    s_acc[BLOCK * 3];           // per pixel: radiance gathered in phase 2
-    __shared__ unsigned long long s_segs;           // the workgroup's segment count
+    __shared__ uint32_t s_next[MASKS ? 1 : BLOCK];  // (!MASKS) per pixel: next global sample index not started
+    __shared__ float4   s_pix[BLOCK * RV];
+    __shared__ float    s_acc[MASKS ? 1 : BLOCK * 3];   // (!MASKS) per pixel: radiance gathered in phase 2
     const int tid = threadIdx.x;
-    if (tid == 0) s_segs = 0;
     if (tid < 4 * R) {
         const int f = tid / R, r = tid - f * R;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -284,10 +314,25 @@ __global__ __launch_bounds__(STATIC_BLOCK) void trace_static_kernel(TraceArgs a,
 
     const int wbase = tid & ~63;
     const int npix = a.height * a.width;
-    const int pixel0 = blockIdx.x * BLOCK;
-    const bool in_canvas = pixel0 + tid < npix;
-    const int pc = in_canvas ? pixel0 + tid : 0;
-    const int pi = pc / a.width, pj = pc - pi * a.width;
+    __syncthreads();                                       // s_mat is staged
+    // A workgroup (one wave) renders tiles of 64 adjacent pixels: tile blockIdx.x, and -- when the launcher keeps the
+    // grid below the number of tiles (a persistent launch: about as many waves as the chip holds) -- further tiles
+    // drawn from a counter until none is left, without leaving its wave slot.  The draw for the NEXT tile is issued
+    // at the start of this one and read at its end, so its latency is never waited for.
+    const int n_tiles = (npix + BLOCK - 1) / BLOCK;
+    const bool persistent = (int)gridDim.x < n_tiles;      // wave-uniform
+    unsigned long long wave_segs = 0;                      // lane 0: the wave's segment count over its tiles
+    for (int tile = blockIdx.x; tile < n_tiles;) {
+    unsigned int drawn = 0;
+    if (persistent && tid == 0) drawn = atomicAdd(a.tile_ctr + blockIdx.y * TILE_CTR_STRIDE, 1u);
+    // (the lane index through an opaque move, once per tile: addresses formed from it are then recomputed per tile
+    // instead of being carried -- as 64-bit per-lane induction pointers and hoisted invariants -- through the hot loop,
+    // which cost 14 VGPRs and the eighth wave per SIMD)
+    int ltid = tid;
+    asm volatile("" : "+v"(ltid));
+    const int pixel0 = tile * BLOCK;
+    const bool in_canvas = pixel0 + ltid < npix;
+    const int pc = in_canvas ? pixel0 + ltid : 0;
     const uint32_t B = (uint32_t)a.max_bounces;
     const uint32_t Bm1 = B - 1u;                    // 1 <= maxBounces (pt_create): the depth cap as one compare
     const uint32_t stride = a.sample_stride;
@@ -301,32 +346,22 @@ __global__ __launch_bounds__(STATIC_BLOCK) void trace_static_kernel(TraceArgs a,
     const uint32_t gs_end = sample_begin + (uint32_t)n_samples * stride;   // first sample index beyond this slice
     const uint32_t ctr_end = gs_end << 6;
 
-    // the fp64 primary search below is counted once, by the launch that executes it
-    unsigned long long segs = in_canvas && slice == 0 && !a.pix_valid ? 1 : 0;
+    unsigned long long segs = 0;
     f3 acc = mk3(0.f, 0.f, 0.f);
     if (in_canvas && !fresh) acc = mk3(canvas[3 * (size_t)pc + 0], canvas[3 * (size_t)pc + 1], canvas[3 * (size_t)pc + 2]);
 
-    // primary segment, once per pixel, fp64 (src/Lib.hs:41-51, :81-98); the same for every launch of this
-    // camera and scene, so the first launch leaves it in a.pix for the later ones
+    // The primary segment (src/Lib.hs:41-51, :81-98) has no jitter and uses no randomness: it is the same for every
+    // sample and every launch of this camera and scene.  primary_fill_kernel (pt_kernels.hip) computes it once per
+    // scene in fp64, in the reference's operation order, and leaves point, direction and record offset in a.pix.
     f3 cd0, cP0;
     int cidxp;
-    if (a.pix_valid) {
+    {
         const float4 q0 = a.pix[2 * (size_t)pc], q1 = a.pix[2 * (size_t)pc + 1];
         cP0 = mk3(q0.x, q0.y, q0.z); cd0 = mk3(q0.w, q1.x, q1.y); cidxp = __float_as_int(q1.z);
-    } else {
-        const PrimaryHit ph = primary_hit(a, pi, pj);
-        cd0 = mk3((float)ph.dx, (float)ph.dy, (float)ph.dz);
-        cP0 = mk3((float)(ph.t * ph.dx), (float)(ph.t * ph.dy), (float)(ph.t * ph.dz));
-        cidxp = 16 * (ph.idx + 1);
-        if (a.pix && in_canvas && slice == 0) {
-            a.pix[2 * (size_t)pc] = make_float4(cP0.x, cP0.y, cP0.z, cd0.x);
-            a.pix[2 * (size_t)pc + 1] = make_float4(cd0.y, cd0.z, __int_as_float(cidxp), 0.f);
-        }
     }
     f3 ccol = mk3(1.f, 1.f, 1.f);
     float ce = 0.f;
     bool traced = in_canvas && cidxp != 0 && B >= 2;      // else every sample is black (src/Lib.hs:68,72)
-    __syncthreads();                                       // s_mat is staged
     if (in_canvas && cidxp != 0) {
         const float4 m0 = matp(cidxp, 0);
         ce = m0.w; ccol = mk3(m0.x, m0.y, m0.z);
@@ -335,22 +370,21 @@ __global__ __launch_bounds__(STATIC_BLOCK) void trace_static_kernel(TraceArgs a,
             traced = false;
         }
     }
-    s_pix[tid * 3 + 0] = make_float4(cP0.x, cP0.y, cP0.z, __int_as_float(cidxp));
-    s_pix[tid * 3 + 1] = make_float4(ccol.x, ccol.y, ccol.z, ce);
-    s_pix[tid * 3 + 2] = make_float4(cd0.x, cd0.y, cd0.z, 0.f);
+    s_pix[ltid * RV + 0] = make_float4(cP0.x, cP0.y, cP0.z, __int_as_float(cidxp));
+    s_pix[ltid * RV + 1] = make_float4(ccol.x, ccol.y, ccol.z, ce);
+    s_pix[ltid * RV + 2] = make_float4(cd0.x, cd0.y, cd0.z, 0.f);
     // LDS byte address of the current pixel's restart record (MASKS: read under exec at every restart, so that
     // the seven constants do not occupy registers through the loop -- 8 waves per SIMD instead of 7)
-    uint32_t raddr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)&s_pix[tid * 3];
+    const uint32_t rbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)&s_pix[0];
+    uint32_t raddr = rbase + (uint32_t)ltid * (RV * 16);
 
-    uint64_t pre = (uint64_t)0xD256D193u * (uint64_t)(uint32_t)pc;
+    uint32_t pre_hi, pre_lo;                               // Philox's first product M * pixel, hoisted out of the loop
+    {
+        const uint64_t pre = (uint64_t)0xD256D193u * (uint64_t)(uint32_t)pc;
+        pre_hi = (uint32_t)(pre >> 32); pre_lo = (uint32_t)pre;
+    }
     f3 o = cP0, d = cd0, thr = ccol;
     int lastp = cidxp;
-    // lane masks of "the primary object is k" and "the last-struck object is k" (closest_static, MASKS)
-#ifdef PT_JIT
-    constexpr bool MASKS = true;      // (8 objects too: their geometry is in the code, not in 64 SGPRs, so the masks fit)
-#else
-    constexpr bool MASKS = NS <= 4;
-#endif
     unsigned long long prim_is[NS], excl[NS];
     auto primary_masks = [&]() {
 #pragma unroll
@@ -365,7 +399,7 @@ __global__ __launch_bounds__(STATIC_BLOCK) void trace_static_kernel(TraceArgs a,
 
     auto scatter = [&](int idxp, float e, f3 din, uint32_t c1, f3 at) -> f3 {
         uint32_t r0, r1;
-        philox2x32_10_pre_v((uint32_t)(pre >> 32), (uint32_t)pre, c1, pregs, r0, r1);
+        philox2x32_10_pre_v(pre_hi, pre_lo, c1, pregs, r0, r1);
         if constexpr (SPEC) {
             const float4 m3 = matp(idxp, 3);
             f3 nrm = mk3(m3.y, m3.z, m3.w);
@@ -379,6 +413,61 @@ __global__ __launch_bounds__(STATIC_BLOCK) void trace_static_kernel(TraceArgs a,
             if (sphere) return scatter_diffuse_about(nrm, r0, r1);
         }
         return scatter_diffuse_bits(matp(idxp, 1), matp(idxp, 2), matp(idxp, 3).x, r0, r1);   // src/Lib.hs:111
+    };
+    // MASKS: the second half of a trip.  The continuing path's values for every lane, then -- for the lanes of `tm`,
+    // whose path ended and restarts as sample c1r >> 6 of the pixel at raddr -- the restart values read in under the
+    // lane mask; scatter; the next trip's _lastStruck masks.
+    auto finish_masks = [&](unsigned long long tm, int kp, float t, const float4 &m0, uint32_t c1, uint32_t c1r,
+                            const unsigned long long *okm) {
+        int idxp; float e; f3 din, hp;
+        // The continuing path's values for every lane, then the restart values read in under the lane
+        // mask from the pixel's LDS record: two ds_read_b128 and one v_mov_b32 where selects would be eight
+        // v_cndmask_b32 (second-port class; tools/ubench_issue.hip) from seven registers held through the loop
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        f4 H = {fmaf(t, d.x, o.x), fmaf(t, d.y, o.y), fmaf(t, d.z, o.z), __int_as_float(kp)};   // march (src/Object.hs:151-153)
+        f4 T = {thr.x * m0.x, thr.y * m0.y, thr.z * m0.z, m0.w};                                // pixel * color (src/Lib.hs:79)
+        unsigned long long saved;
+        if constexpr (SPEC) {                          // the specular bounce also reads the incoming direction
+            f4 D = {d.x, d.y, d.z, 0.f};
+            asm volatile("s_and_saveexec_b64 %[sv], %[m]\n\t"
+                         "ds_read_b128 %[H], %[ad]\n\t"
+                         "ds_read_b128 %[T], %[ad] offset:16\n\t"
+                         "ds_read_b128 %[D], %[ad] offset:32\n\t"
+                         "v_mov_b32 %[c], %[cr]\n\t"
+                         "s_waitcnt lgkmcnt(0)\n\t"
+                         "s_mov_b64 exec, %[sv]"
+                         : [H] "+v"(H), [T] "+v"(T), [D] "+v"(D), [c] "+v"(c1), [sv] "=&s"(saved)
+                         : [m] "s"(tm), [ad] "v"(raddr), [cr] "v"(c1r) : "memory");
+            din = mk3(D.x, D.y, D.z);
+            thr = mk3(T.x, T.y, T.z); e = T.w;
+        } else {
+            // (the diffuse bounce does not read the tag: a 96-bit read straight into the throughput's registers;
+            // with the tag as a fourth element hipcc formed the tuple elsewhere and copied it back, 3 v_mov)
+            typedef float f3v __attribute__((ext_vector_type(3)));
+            f3v T3 = {thr.x * m0.x, thr.y * m0.y, thr.z * m0.z};
+            asm volatile("s_and_saveexec_b64 %[sv], %[m]\n\t"
+                         "ds_read_b128 %[H], %[ad]\n\t"
+                         "ds_read_b96 %[T], %[ad] offset:16\n\t"
+                         "v_mov_b32 %[c], %[cr]\n\t"
+                         "s_waitcnt lgkmcnt(0)\n\t"
+                         "s_mov_b64 exec, %[sv]"
+                         : [H] "+v"(H), [T] "+v"(T3), [c] "+v"(c1), [sv] "=&s"(saved)
+                         : [m] "s"(tm), [ad] "v"(raddr), [cr] "v"(c1r) : "memory");
+            din = d;
+            thr = mk3(T3.x, T3.y, T3.z); e = m0.w;
+        }
+        hp = mk3(H.x, H.y, H.z); idxp = __float_as_int(H.w);
+        d = scatter(idxp, e, din, c1, hp);
+        o = hp; lastp = idxp; ctr = c1 + 1u;
+        // next trip's _lastStruck masks: the primary object where the path restarts, else this
+        // trip's winner = the LAST object that was accepted
+        unsigned long long later = 0;
+#pragma unroll
+        for (int k = NS - 1; k >= 0; --k) {
+            const unsigned long long won = okm[k] & ~later;
+            later |= okm[k];
+            excl[k] = (tm & prim_is[k]) | (won & ~tm);
+        }
     };
     // One segment.  `draw(terminal, c1, c1r)` decides what a finished path does next
     // and returns in c1r the counter word (sample << 6 | 0) of a restarted path.
@@ -411,46 +500,10 @@ __global__ __launch_bounds__(STATIC_BLOCK) void trace_static_kernel(TraceArgs a,
         if constexpr (MASKS) {
             if (!decltype(all_alive)::value) tm = __builtin_amdgcn_ballot_w64(terminal);   // phase 2's draw rewrites it
         }
-        int idxp; float e; f3 din, hp;
         if constexpr (MASKS) {
-            // The continuing path's values for every lane, then the restart values read in under the lane
-            // mask from the pixel's LDS record: two ds_read_b128 and one v_mov_b32 where selects would be eight
-            // v_cndmask_b32 (second-port class; tools/ubench_issue.hip) from seven registers held through the loop
-            typedef float f4 __attribute__((ext_vector_type(4)));
-            f4 H = {fmaf(t, d.x, o.x), fmaf(t, d.y, o.y), fmaf(t, d.z, o.z), __int_as_float(kp)};   // march (src/Object.hs:151-153)
-            f4 T = {thr.x * m0.x, thr.y * m0.y, thr.z * m0.z, m0.w};                                // pixel * color (src/Lib.hs:79)
-            unsigned long long saved;
-            if constexpr (SPEC) {                          // the specular bounce also reads the incoming direction
-                f4 D = {d.x, d.y, d.z, 0.f};
-                asm volatile("s_and_saveexec_b64 %[sv], %[m]\n\t"
-                             "ds_read_b128 %[H], %[ad]\n\t"
-                             "ds_read_b128 %[T], %[ad] offset:16\n\t"
-                             "ds_read_b128 %[D], %[ad] offset:32\n\t"
-                             "v_mov_b32 %[c], %[cr]\n\t"
-                             "s_waitcnt lgkmcnt(0)\n\t"
-                             "s_mov_b64 exec, %[sv]"
-                             : [H] "+v"(H), [T] "+v"(T), [D] "+v"(D), [c] "+v"(c1), [sv] "=&s"(saved)
-                             : [m] "s"(tm), [ad] "v"(raddr), [cr] "v"(c1r) : "memory");
-                din = mk3(D.x, D.y, D.z);
-                thr = mk3(T.x, T.y, T.z); e = T.w;
-            } else {
-                // (the diffuse bounce does not read the tag: a 96-bit read straight into the throughput's registers;
-                // with the tag as a fourth element hipcc formed the tuple elsewhere and copied it back, 3 v_mov)
-                typedef float f3v __attribute__((ext_vector_type(3)));
-                f3v T3 = {thr.x * m0.x, thr.y * m0.y, thr.z * m0.z};
-                asm volatile("s_and_saveexec_b64 %[sv], %[m]\n\t"
-                             "ds_read_b128 %[H], %[ad]\n\t"
-                             "ds_read_b96 %[T], %[ad] offset:16\n\t"
-                             "v_mov_b32 %[c], %[cr]\n\t"
-                             "s_waitcnt lgkmcnt(0)\n\t"
-                             "s_mov_b64 exec, %[sv]"
-                             : [H] "+v"(H), [T] "+v"(T3), [c] "+v"(c1), [sv] "=&s"(saved)
-                             : [m] "s"(tm), [ad] "v"(raddr), [cr] "v"(c1r) : "memory");
-                din = d;
-                thr = mk3(T3.x, T3.y, T3.z); e = m0.w;
-            }
-            hp = mk3(H.x, H.y, H.z); idxp = __float_as_int(H.w);
+            finish_masks(tm, kp, t, m0, c1, c1r, okm);
         } else {
+            int idxp; float e; f3 din, hp;
             c1 = terminal ? c1r : c1;
             idxp = terminal ? cidxp : kp;
             e    = terminal ? ce : m0.w;
@@ -461,19 +514,8 @@ __global__ __launch_bounds__(STATIC_BLOCK) void trace_static_kernel(TraceArgs a,
             thr = mk3(terminal ? ccol.x : thr.x * m0.x,                            // pixel * color (src/Lib.hs:79)
                       terminal ? ccol.y : thr.y * m0.y,
                       terminal ? ccol.z : thr.z * m0.z);
-        }
-        d = scatter(idxp, e, din, c1, hp);
-        o = hp; lastp = idxp; ctr = c1 + 1u;
-        if constexpr (MASKS) {
-            // next trip's _lastStruck masks: the primary object where the path restarts, else this
-            // trip's winner = the LAST object that was accepted
-            unsigned long long later = 0;
-#pragma unroll
-            for (int k = NS - 1; k >= 0; --k) {
-                const unsigned long long won = okm[k] & ~later;
-                later |= okm[k];
-                excl[k] = (tm & prim_is[k]) | (won & ~tm);
-            }
+            d = scatter(idxp, e, din, c1, hp);
+            o = hp; lastp = idxp; ctr = c1 + 1u;
         }
     };
 
@@ -497,70 +539,178 @@ __global__ __launch_bounds__(STATIC_BLOCK) void trace_static_kernel(TraceArgs a,
     // (its sample index is gs_end); it enters phase 2 pathless.
 
     // ---- phase 2: the wave shares what is left -------------------------------
-    s_next[tid] = alive ? (ctr >> 6) + stride : gs_end;
-    s_acc[tid * 3 + 0] = 0.f; s_acc[tid * 3 + 1] = 0.f; s_acc[tid * 3 + 2] = 0.f;
-    __syncthreads();
-    int cur = tid;                                         // the pixel (workgroup-relative) this lane works on
-    bool dry = false;                                      // wave-uniform: no pixel has an unstarted sample
-    if (__ballot(alive) != 0ull || !dry) do {
-        trip(false_type{}, [&](bool &terminal, uint32_t &c1, uint32_t &c1r) {
-            uint32_t g = gs_end;
-            if (terminal) g = atomicAdd(&s_next[cur], stride);           // next sample of my current pixel
-            const bool want = terminal || !alive;          // lanes that need a (new) path
-            bool needy = want && !(terminal && g < gs_end);
-            const bool adopting = !dry && __ballot(needy) != 0ull;
-            while (!dry && __ballot(needy) != 0ull) {
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-                const bool has = __hip_atomic_load(&s_next[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < gs_end;
-                const unsigned long long avail = __ballot(has);      // pixels of this wave with unstarted samples
-                if (avail == 0ull) { dry = true; break; }
-                const int v = wbase + (__ffsll((long long)avail) - 1);   // wave-uniform choice of pixel to help
-                if (needy) {
-                    g = atomicAdd(&s_next[v], stride);
-                    if (g < gs_end) {
-                        if (v != cur) {                    // hand over what was gathered, adopt pixel v
-                            atomicAdd(&s_acc[cur * 3 + 0], acc.x);
-                            atomicAdd(&s_acc[cur * 3 + 1], acc.y);
-                            atomicAdd(&s_acc[cur * 3 + 2], acc.z);
-                            acc = mk3(0.f, 0.f, 0.f);
-                            cur = v;
-                            raddr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)&s_pix[v * 3];
-                            const float4 p0 = s_pix[v * 3 + 0];
-                            cidxp = __float_as_int(p0.w);
-                            if constexpr (!MASKS) {        // the select form keeps the restart constants in registers
-                                const float4 p1 = s_pix[v * 3 + 1], p2 = s_pix[v * 3 + 2];
-                                cP0 = mk3(p0.x, p0.y, p0.z); ccol = mk3(p1.x, p1.y, p1.z); ce = p1.w;
-                                cd0 = mk3(p2.x, p2.y, p2.z);
+    unsigned long long nseg2 = 0;                          // wave-uniform: searches of phase 2 (MASKS)
+    if constexpr (MASKS) {
+        // Everything of this phase is a lane mask on the scalar unit or lives in the pixel's LDS record, so a trip
+        // costs what a phase-1 trip does plus one LDS atomic under exec, a shift and a compare -- unless a lane
+        // needs a pixel to help, which takes the wave through the adoption loop below.
+        //   alive_m : lanes with a path in flight.  A lane without one keeps executing the trip on whatever its
+        //             registers hold, with a throughput of zero (it adds nothing) and outside every mask.
+        //   draw    : a lane whose path ended takes the next sample of the pixel it works on with ds_add_rtn_u32 on
+        //             the record's counter ([2].w), under exec.
+        //   adopt   : lanes left without a sample pick -- wave-uniformly, s_ff1 on the ballot of pixels that still
+        //             have unstarted samples -- a pixel v, draw from its counter, hand what they gathered to their
+        //             old pixel's record ([3].xyz, ds_add_f32) and point raddr at v's record; Philox's pixel product
+        //             and the primary-object masks of the movers are wave-uniform values (one pixel), set from SGPRs.
+        const uint32_t own = rbase + (uint32_t)ltid * (RV * 16);
+        lds_write_u32(own + 44, alive ? (ctr >> 6) + stride : gs_end);
+        s_pix[ltid * RV + 3] = make_float4(0.f, 0.f, 0.f, 0.f);
+        unsigned long long alive_m = __builtin_amdgcn_ballot_w64(alive);
+        thr = mk3(alive ? thr.x : 0.f, alive ? thr.y : 0.f, alive ? thr.z : 0.f);
+        const uint32_t stride_v = to_vgpr(stride);
+        bool dry = false;                                  // wave-uniform: no pixel has an unstarted sample
+        if (alive_m != 0ull) do {
+            int kp; float t;
+            unsigned long long okm[NS];
+            closest_static<NS, SPEC, true>(sg, a.rect, o, d, lastp, excl, okm, kp, t);
+            nseg2 += (unsigned)__builtin_popcountll(alive_m);
+            const float4 m0 = matp(kp, 0);
+            // miss (tag 0, src/Lib.hs:72), light (tag e > 0, :74) or the depth cap (:68) end the path
+            unsigned long long tm = (__builtin_amdgcn_ballot_w64(m0.w >= 0.f) |
+                                     __builtin_amdgcn_ballot_w64((ctr & 63u) >= Bm1)) & alive_m;
+            {                                              // emittance * pixel (src/Lib.hs:74); a pathless lane's pixel is 0
+                const float E = __int_as_float(max(__float_as_int(m0.w), 0));
+                acc.x = fmaf(E, thr.x, acc.x);
+                acc.y = fmaf(E, thr.y, acc.y);
+                acc.z = fmaf(E, thr.z, acc.z);
+            }
+            const uint32_t c1 = ctr;
+            uint32_t g = lds_add_rtn_under<44>(tm, raddr, stride_v, c1);       // next sample of the lane's current pixel
+            unsigned long long want = (__builtin_amdgcn_ballot_w64(g >= gs_end) & tm) | (everyone & ~alive_m);
+            unsigned long long got = 0;
+            if (want != 0ull && !dry) {
+                do {
+                    const unsigned long long avail = __builtin_amdgcn_ballot_w64(lds_read_u32(own + 44) < gs_end);
+                    if (avail == 0ull) { dry = true; break; }
+                    const uint32_t v = (uint32_t)__builtin_ctzll(avail);               // wave-uniform choice of pixel to help
+                    const uint32_t rv = rbase + v * (RV * 16);
+                    const uint32_t g2 = lds_add_rtn_under<44>(want, to_vgpr(rv), stride_v, g);
+                    const unsigned long long gotnow = __builtin_amdgcn_ballot_w64(g2 < gs_end) & want;
+                    const unsigned long long mv = gotnow & __builtin_amdgcn_ballot_w64(raddr != rv);
+                    if (mv != 0ull) {                      // hand over what was gathered, adopt pixel v
+                        const uint64_t pre = (uint64_t)0xD256D193u * (uint64_t)(uint32_t)(pixel0 + (int)v);
+                        const uint32_t phi = (uint32_t)(pre >> 32), plo = (uint32_t)pre;
+                        unsigned long long saved;
+                        asm volatile("s_and_saveexec_b64 %[sv], %[m]\n\t"
+                                     "ds_add_f32 %[ra], %[ax] offset:48\n\t"
+                                     "ds_add_f32 %[ra], %[ay] offset:52\n\t"
+                                     "ds_add_f32 %[ra], %[az] offset:56\n\t"
+                                     "v_mov_b32 %[ra], %[rv]\n\t"
+                                     "v_mov_b32 %[ph], %[sph]\n\t"
+                                     "v_mov_b32 %[pl], %[spl]\n\t"
+                                     "s_nop 1\n\t"
+                                     "v_mov_b32 %[ax], 0\n\t"
+                                     "v_mov_b32 %[ay], 0\n\t"
+                                     "v_mov_b32 %[az], 0\n\t"
+                                     "s_mov_b64 exec, %[sv]"
+                                     : [ax] "+v"(acc.x), [ay] "+v"(acc.y), [az] "+v"(acc.z), [ra] "+v"(raddr),
+                                       [ph] "+v"(pre_hi), [pl] "+v"(pre_lo), [sv] "=&s"(saved)
+                                     : [m] "s"(mv), [rv] "s"(rv), [sph] "s"(phi), [spl] "s"(plo) : "memory");
+                        const int idx_v = __builtin_amdgcn_readfirstlane((int)lds_read_u32(rv + 12));
+#pragma unroll
+                        for (int k = 0; k < NS; ++k)
+                            prim_is[k] = (prim_is[k] & ~mv) | (idx_v == 16 * (k + 1) ? mv : 0ull);
+                    }
+                    g = pick(gotnow, g2, g);
+                    got |= gotnow;
+                    want &= ~gotnow;
+                } while (want != 0ull);
+            }
+            // want: lanes that asked and got nothing -- no path from here on
+            const unsigned long long dying = want & alive_m;
+            tm = (tm & ~want) | got;                       // restart from the (current) pixel's primary hit
+            alive_m = (alive_m & ~want) | got;
+            finish_masks(tm, kp, t, m0, c1, g << 6, okm);
+            if (dying != 0ull) {
+                const bool gone = lane_of(dying);
+                thr = mk3(gone ? 0.f : thr.x, gone ? 0.f : thr.y, gone ? 0.f : thr.z);
+            }
+        } while (alive_m != 0ull);
+        {   // what the lane still holds goes to the record of the pixel it worked on last
+            asm volatile("ds_add_f32 %[ra], %[ax] offset:48\n\t"
+                         "ds_add_f32 %[ra], %[ay] offset:52\n\t"
+                         "ds_add_f32 %[ra], %[az] offset:56\n\t"
+                         "s_waitcnt lgkmcnt(0)"
+                         : : [ra] "v"(raddr), [ax] "v"(acc.x), [ay] "v"(acc.y), [az] "v"(acc.z) : "memory");
+        }
+    } else {
+        s_next[ltid] = alive ? (ctr >> 6) + stride : gs_end;
+        s_acc[ltid * 3 + 0] = 0.f; s_acc[ltid * 3 + 1] = 0.f; s_acc[ltid * 3 + 2] = 0.f;
+        __syncthreads();
+        int cur = ltid;                                         // the pixel (workgroup-relative) this lane works on
+        bool dry = false;                                      // wave-uniform: no pixel has an unstarted sample
+        if (__ballot(alive) != 0ull || !dry) do {
+            trip(false_type{}, [&](bool &terminal, uint32_t &c1, uint32_t &c1r) {
+                uint32_t g = gs_end;
+                if (terminal) g = atomicAdd(&s_next[cur], stride);           // next sample of my current pixel
+                const bool want = terminal || !alive;          // lanes that need a (new) path
+                bool needy = want && !(terminal && g < gs_end);
+                const bool adopting = !dry && __ballot(needy) != 0ull;
+                while (!dry && __ballot(needy) != 0ull) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                    const bool has = __hip_atomic_load(&s_next[ltid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < gs_end;
+                    const unsigned long long avail = __ballot(has);      // pixels of this wave with unstarted samples
+                    if (avail == 0ull) { dry = true; break; }
+                    const int v = wbase + (__ffsll((long long)avail) - 1);   // wave-uniform choice of pixel to help
+                    if (needy) {
+                        g = atomicAdd(&s_next[v], stride);
+                        if (g < gs_end) {
+                            if (v != cur) {                    // hand over what was gathered, adopt pixel v
+                                atomicAdd(&s_acc[cur * 3 + 0], acc.x);
+                                atomicAdd(&s_acc[cur * 3 + 1], acc.y);
+                                atomicAdd(&s_acc[cur * 3 + 2], acc.z);
+                                acc = mk3(0.f, 0.f, 0.f);
+                                cur = v;
+                                raddr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)&s_pix[v * RV];
+                                const float4 p0 = s_pix[v * RV + 0];
+                                cidxp = __float_as_int(p0.w);
+                                if constexpr (!MASKS) {        // the select form keeps the restart constants in registers
+                                    const float4 p1 = s_pix[v * RV + 1], p2 = s_pix[v * RV + 2];
+                                    cP0 = mk3(p0.x, p0.y, p0.z); ccol = mk3(p1.x, p1.y, p1.z); ce = p1.w;
+                                    cd0 = mk3(p2.x, p2.y, p2.z);
+                                }
+                                const uint64_t pre = (uint64_t)0xD256D193u * (uint64_t)(uint32_t)(pixel0 + v);
+                                pre_hi = (uint32_t)(pre >> 32); pre_lo = (uint32_t)pre;
                             }
-                            pre = (uint64_t)0xD256D193u * (uint64_t)(uint32_t)(pixel0 + v);
+                            needy = false;
                         }
-                        needy = false;
                     }
                 }
-            }
-            if (MASKS && adopting) primary_masks();        // lanes may have moved to another pixel
-            alive = !want || !needy;                       // path continues, or a sample was drawn
-            terminal = want && !needy;                     // restart from the (current) pixel's primary hit
-            c1r = g << 6;
-        });
-    } while (__ballot(alive) != 0ull || !dry);
+                if (MASKS && adopting) primary_masks();        // lanes may have moved to another pixel
+                alive = !want || !needy;                       // path continues, or a sample was drawn
+                terminal = want && !needy;                     // restart from the (current) pixel's primary hit
+                c1r = g << 6;
+            });
+        } while (__ballot(alive) != 0ull || !dry);
 
-    atomicAdd(&s_acc[cur * 3 + 0], acc.x);
-    atomicAdd(&s_acc[cur * 3 + 1], acc.y);
-    atomicAdd(&s_acc[cur * 3 + 2], acc.z);
+        atomicAdd(&s_acc[cur * 3 + 0], acc.x);
+        atomicAdd(&s_acc[cur * 3 + 1], acc.y);
+        atomicAdd(&s_acc[cur * 3 + 2], acc.z);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) segs += __shfl_down(segs, off, 64);
+    wave_segs += segs + nseg2;
+    __syncthreads();
+    if (in_canvas) {
+        if constexpr (MASKS) {
+            const float4 q = s_pix[ltid * RV + 3];
+            canvas[3 * (size_t)pc + 0] = q.x;
+            canvas[3 * (size_t)pc + 1] = q.y;
+            canvas[3 * (size_t)pc + 2] = q.z;
+        } else {
+            canvas[3 * (size_t)pc + 0] = s_acc[ltid * 3 + 0];
+            canvas[3 * (size_t)pc + 1] = s_acc[ltid * 3 + 1];
+            canvas[3 * (size_t)pc + 2] = s_acc[ltid * 3 + 2];
+        }
+    }
+    __syncthreads();                                       // the records are free for the next tile
+    if (!persistent) break;
+    tile = (int)gridDim.x + (int)((unsigned int)__builtin_amdgcn_readfirstlane((int)drawn) - a.tile_base[blockIdx.y]);
+    }
     // one global atomic per workgroup for the segment counter: 32,400 same-address
     // atomics (one per wave) serialise in L2 when a short launch's workgroups
     // retire together
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) segs += __shfl_down(segs, off, 64);
-    if ((tid & 63) == 0 && segs) atomicAdd(&s_segs, segs);
-    __syncthreads();
-    if (in_canvas) {
-        canvas[3 * (size_t)pc + 0] = s_acc[tid * 3 + 0];
-        canvas[3 * (size_t)pc + 1] = s_acc[tid * 3 + 1];
-        canvas[3 * (size_t)pc + 2] = s_acc[tid * 3 + 2];
-    }
-    if (tid == 0 && s_segs) atomicAdd(seg_lane(a.segments), s_segs);
+    if (tid == 0 && wave_segs) atomicAdd(seg_lane(a.segments), wave_segs);
 }
 
 #ifdef PT_JIT
