@@ -215,6 +215,14 @@ def main():
     ap.add_argument("--pipeline-depth", type=int, default=2, choices=(2, 3),
                     help="frames in flight (canvases and trace streams).  3 measured 1-4 %% slower than 2 on one GPU with "
                          "libpt's all-reduce over a world of 1 in the loop (tools/pipeline_depth_ab.sh, DESIGN.md 6)")
+    ap.add_argument("--comm-shared", action="store_true",
+                    help="N > 1, libpt collective: one RCCL communicator per rank shared by its pipelined contexts "
+                         "(pt_comm_share) instead of one per context.  Measured on one GPU (RCCL world of 1, a rank's "
+                         "128-spp share): 1.54 against 1.45 ms per step -- RCCL orders the launches of one communicator "
+                         "across streams, which ties frame k+1's all-reduce to frame k's (profiles/r03_frame_pipeline.txt)")
+    ap.add_argument("--gate", action="store_true",
+                    help="a frame's trace starts when the frame before it has dispatched its last workgroup (pt_trace_gate) "
+                         "instead of whenever its canvas is free; measured to change the overlap, not the throughput")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="trace, all-reduce and output strictly in line instead of overlapped with the next frame")
     ap.add_argument("--watchdog-s", type=float, default=900.0,
@@ -339,11 +347,11 @@ def main():
     canvas = canvases[0]
     rgbs = [torch.empty(args.height * args.width * 3, dtype=torch.uint8, device="cuda") for _ in rs]
     rgb = rgbs[0]
-    # The frame's collective.  libpt: ONE RCCL communicator per rank -- the first context joins it with rank 0's id,
-    # handed round over gloo, and the other contexts of the frame pipeline share it (pt_comm_share: frames k and k+1
-    # are in flight on two streams, their all-reduces run in the order they were queued).  If RCCL cannot be
-    # reached through libpt on this machine every rank falls back to torch's all-reduce together, and the JSON
-    # line says which one ran.
+    # The frame's collective.  libpt: one RCCL communicator per pipelined context (frames k and k+1 are in flight on
+    # two streams), each joined with an id of rank 0's handed round over gloo; --comm-shared: ONE per rank, which
+    # the other contexts share (pt_comm_share) -- fewer channels and proxies, but measured 6 % slower per step on
+    # one GPU because RCCL then orders the two streams' launches.  If RCCL cannot be reached through libpt on this
+    # machine every rank falls back to torch's all-reduce together, and the JSON line says which one ran.
     collective, comm, comm_per_ctx = None, {}, []
     if multi:
         collective = args.collective
@@ -352,10 +360,16 @@ def main():
         if collective == "libpt":
             def init_rank(uid, rk, n):
                 rs[0].comm_init_rank(uid, rk, n)
-                for q in rs[1:]:
-                    q.comm_share(rs[0])
+                if args.comm_shared:
+                    for q in rs[1:]:
+                        q.comm_share(rs[0])
             ok, _ = agree_on_libpt_collective(dist, rank, world, pa.Renderer.comm_unique_id, init_rank,
                                               own_world_of_one=rehearsal)
+            if ok and not args.comm_shared:           # further communicators, one per remaining context
+                for q in rs[1:]:
+                    ok = ok and agree_on_libpt_collective(dist, rank, world, pa.Renderer.comm_unique_id,
+                                                          lambda uid, rk, n, q=q: q.comm_init_rank(uid, rk, n),
+                                                          own_world_of_one=rehearsal)[0]
             if ok:
                 comm_per_ctx = [q.comm_info() for q in rs]
                 comm = comm_per_ctx[0]
@@ -380,7 +394,8 @@ def main():
         return dist.all_reduce(cv, op=dist.ReduceOp.SUM, group=nccl_group, async_op=True)
 
     pipe = PipelinedFrames(rs, canvases, rgbs, rank=rank, spp_total=args.spp, my_spp=my_spp,
-                           mode=pa.PT_RGB8_MEAN_CLAMP, allreduce=allreduce if multi else None) if pipelined else None
+                           mode=pa.PT_RGB8_MEAN_CLAMP, allreduce=allreduce if multi else None,
+                           gate=args.gate) if pipelined else None
 
     def step():
         if pipe is not None:
@@ -498,8 +513,9 @@ def main():
                        "visible_devices": torch.cuda.device_count(),
                        "collective": None if not multi else
                                      (f"libpt ncclAllReduce behind the C ABI (pt_allreduce_sum), {comm.get('n_ranks')} RCCL ranks, "
-                                      f"RCCL version code {comm.get('rccl_version')}, one communicator per rank shared by its "
-                                      f"{len(rs)} context(s) (pt_comm_share)"
+                                      f"RCCL version code {comm.get('rccl_version')}, "
+                                      + (f"one communicator per context ({len(rs)} per rank)" if not args.comm_shared else
+                                         f"one communicator per rank shared by its {len(rs)} context(s) (pt_comm_share)")
                                       + ("; REHEARSAL on one GPU: a communicator of ONE rank per rank process, frames are NOT combined"
                                          if rehearsal else "") if collective == "libpt"
                                       else "torch.distributed all_reduce (nccl = RCCL)" if collective == "torch" else collective)
@@ -517,8 +533,10 @@ def main():
                        "value_mode": "wall time of K pipelined frames (barrier + device synchronize on both sides, "
                                      "max over ranks); consecutive frames overlap on two streams"
                                      if pipe is not None else "wall time of K in-line frames",
-                       "frame_pipeline": f"{len(rs)} frames in flight ({len(rs)} canvases and trace streams): all-reduce + output "
-                                         "of frame k overlap the trace of the next" if pipe is not None else "none"},
+                       "frame_pipeline": (f"{len(rs)} frames in flight ({len(rs)} canvases and trace streams): all-reduce + output "
+                                          "of frame k overlap the trace of the next; "
+                                          + ("frame k+1's trace starts when frame k's has dispatched its last workgroup (pt_trace_gate)"
+                                             if pipe.gate else "no drain gate")) if pipe is not None else "none"},
             "roofline": {"bound": "valu", "achieved": round(achieved, 3), "peak": FP32_VALU_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / FP32_VALU_PEAK_TFLOPS, 4),
                          "traffic": traffic,

@@ -297,6 +297,23 @@ int pt_jit_cache_size(void);
 int pt_set_timing(pt_ctx *ctx, int32_t enable);
 int pt_last_trace_ms(pt_ctx *ctx, float *ms, int32_t *launches);
 
+/* Frames in flight on one GPU (the pull-next-frame loop of app/Web.hs:42-65 made
+ * asynchronous: frame k+1 is traced into one context while frame k's all-reduce
+ * and output run on another).  Two trace launches that run at the same time on
+ * two streams share the GPU evenly, finish together and leave it idle together
+ * while their last waves end; what a frame loop wants is that the next launch
+ * starts exactly when the current one has no work left to hand out.
+ * pt_trace_gate(ctx, after) queues on ctx's stream a wait for that moment of
+ * `after`'s most recent pt_trace (its last launch: the workgroup dispatched last
+ * writes a word the wait polls; hipStreamWaitValue64): what is queued on ctx's
+ * stream afterwards -- the next frame's pt_trace -- then fills the wave slots
+ * that `after`'s launch leaves as it drains.  Call it after `after`'s pt_trace
+ * has been called (the wait names work that is already queued, so no cycle can
+ * form); `after` must outlive the wait.  Same device only.  PT_OK and no wait if
+ * `after` has traced nothing yet; PT_ERR_UNSUPPORTED where the device cannot
+ * make a stream wait for a value.  No counterpart in the reference. */
+int pt_trace_gate(pt_ctx *ctx, pt_ctx *after);
+
 /* ---- Multi-GPU ----------------------------------------------
  * The reference has ONE `traces` (src/Lib.hs:53-56), read by app/Write.hs:24-28
  * and app/Web.hs:42-65; these entry points keep it one however many GPUs render

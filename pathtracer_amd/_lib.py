@@ -94,6 +94,7 @@ SIGNATURES = {
     "pt_comm_unique_id": (C.c_int, [_P]),
     "pt_comm_init_rank": (C.c_int, [_P, _P, C.c_int32, C.c_int32]),
     "pt_comm_share": (C.c_int, [_P, _P]),
+    "pt_trace_gate": (C.c_int, [_P, _P]),
     "pt_allreduce_sum": (C.c_int, [_P]),
     "pt_comm_info": (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "pt_last_error": (C.c_char_p, [_P]),

@@ -244,7 +244,7 @@ void pt_destroy(pt_ctx *c)
     if (c->d_rect) (void)hipFree(c->d_rect);
     if (c->d_partial) (void)hipFree(c->d_partial);
     if (c->d_pix) (void)hipFree(c->d_pix);
-    if (c->d_tile_ctr) (void)hipFree(c->d_tile_ctr);
+    if (c->d_gate) (void)hipFree(c->d_gate);
     if (c->d_bvh_nodes) (void)hipFree(c->d_bvh_nodes);
     if (c->d_bvh_prims) (void)hipFree(c->d_bvh_prims);
     if (c->d_bvh_geom) (void)hipFree(c->d_bvh_geom);
@@ -428,9 +428,13 @@ int pt::trace_block(pt_ctx *c, int64_t k_begin, int32_t iters)
             return fail(c, PT_ERR_HIP, std::string("pt_trace: hipMalloc(primary hits): ") + hipGetErrorString(e));
         }
     }
-    if (static_path && !c->d_tile_ctr) {
-        PT_HIP(c, hipMalloc((void **)&c->d_tile_ctr, MAX_SLICES * TILE_CTR_STRIDE * sizeof(unsigned int)));
-        PT_HIP(c, hipMemsetAsync(c->d_tile_ctr, 0, MAX_SLICES * TILE_CTR_STRIDE * sizeof(unsigned int), c->stream));
+    if (!c->d_gate) {                                // the drain gate's word; without it launches simply do not signal
+        if (hipExtMallocWithFlags((void **)&c->d_gate, 8, hipMallocSignalMemory) != hipSuccess &&
+            hipMalloc((void **)&c->d_gate, 8) != hipSuccess) c->d_gate = nullptr;
+        (void)hipGetLastError();
+        if (c->d_gate && hipStreamWriteValue64(c->stream, c->d_gate, 0, 0) != hipSuccess) {
+            (void)hipGetLastError(); (void)hipFree(c->d_gate); c->d_gate = nullptr;
+        }
     }
     if (c->timing) PT_HIP(c, hipEventRecord(c->ev0, c->stream));
     int launches = 0;
@@ -447,12 +451,13 @@ int pt::trace_block(pt_ctx *c, int64_t k_begin, int32_t iters)
         a.n_samples = n;
         a.partial = c->d_partial;
         a.pix = static_path ? c->d_pix : nullptr; a.pix_valid = a.pix && c->pix_valid ? 1 : 0;
-        a.tile_ctr = static_path ? c->d_tile_ctr : nullptr;
+        a.gate = c->d_gate; a.gate_value = c->gate_seq + 1;
         PT_HIP(c, launch_trace(a, c->h_geom.data(), reuse, c->has_specular,
                                (c->p.flags & PT_FLAG_LDS_TILES) != 0,
                                (c->p.flags & PT_FLAG_NO_STEAL) == 0, c->stream,
-                               static_path ? c->scene_kernel : nullptr, c->tile_base));
+                               static_path ? c->scene_kernel : nullptr));
         if (a.pix) c->pix_valid = true;              // later launches on this stream read what this one stored
+        if (c->d_gate) c->gate_seq += 1;
         c->canvas_stale = false;
         c->samples_done += n;
         k_begin += n;
@@ -710,6 +715,22 @@ int pt_set_stream(pt_ctx *c, void *hip_stream)
     if (c->group) return fail(c, PT_ERR_UNSUPPORTED, "pt_set_stream: a pt_create_multi context launches on its members' own streams");
     PT_HIP(c, hipStreamSynchronize(c->stream));
     c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return PT_OK;
+}
+
+int pt_trace_gate(pt_ctx *c, pt_ctx *after)
+{
+    if (int s = check_ctx(c)) return s;
+    if (!after || after == c) return fail(c, PT_ERR_INVALID, "pt_trace_gate: need another context");
+    if (c->group || after->group) return fail(c, PT_ERR_UNSUPPORTED, "pt_trace_gate: not for pt_create_multi contexts");
+    if (c->p.device != after->p.device) return fail(c, PT_ERR_INVALID, "pt_trace_gate: the contexts are on different devices");
+    if (!after->d_gate || after->gate_seq == 0) return PT_OK;         // nothing traced there yet: nothing to wait for
+    int can = 0;
+    if (hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, c->p.device) != hipSuccess || !can) {
+        (void)hipGetLastError();
+        return fail(c, PT_ERR_UNSUPPORTED, "pt_trace_gate: this device cannot make a stream wait for a value (hipStreamWaitValue64)");
+    }
+    PT_HIP(c, hipStreamWaitValue64(c->stream, after->d_gate, after->gate_seq, hipStreamWaitValueGte, ~0ull));
     return PT_OK;
 }
 

@@ -23,8 +23,8 @@ struct pt_ctx {
     double *d_prim = nullptr;
     float4 *d_pix = nullptr;           // primary hits kept across launches (TraceArgs::pix); valid until the next scene upload
     bool pix_valid = false;
-    unsigned int *d_tile_ctr = nullptr;   // tile counters of persistent launches (TraceArgs::tile_ctr), zeroed once
-    unsigned int tile_base[pt::MAX_SLICES] = {};   // their running values as the launches of this context leave them
+    unsigned long long *d_gate = nullptr;   // the drain gate's word (TraceArgs::gate), signal memory where the runtime has it
+    unsigned long long gate_seq = 0;        // value the most recent trace launch of this context writes there
     float *d_partial = nullptr;        // sample-slice planes of a launch (pt_internal.hpp), allocated at the first large pt_trace
     float4 *d_rect = nullptr;          // sides of Rectangle forms, 2 float4 per object; null without one
     float4 *d_bvh_nodes = nullptr;               // spatial index over the finite forms (pt_bvh.hpp), or null

@@ -23,7 +23,6 @@ template <int NS> struct StaticGeom {
 constexpr int MAX_SLICES = 2;
 constexpr int SLICE_MIN_SAMPLES = 512;        // smaller launches are not sliced: the second set-up pass costs what the
                                               // drain saves (and more when consecutive frames overlap: 256 spp +2 %, 128 spp +8 %)
-constexpr int TILE_CTR_STRIDE = 32;            // in counters (128 bytes)
 constexpr int SEG_LANES = 64;
 constexpr int SEG_LANE_STRIDE = 16;                 // in counters (128 bytes)
 constexpr int SEG_EPOCH = SEG_LANES * SEG_LANE_STRIDE;
@@ -59,12 +58,11 @@ struct TraceArgs {
     float   *partial;                  // (MAX_SLICES - 1) * H*W*3 floats, or null: no slicing
     int      n_slices;
     int      slice_j0[MAX_SLICES], slice_n[MAX_SLICES];
-    // Persistent launch of trace_static_kernel (grid smaller than the number of 64-pixel tiles): workgroup b renders
-    // tile b first and takes further tiles from a counter per slice, tile = gridDim.x + (old counter value -
-    // tile_base[slice]); the counters are never reset -- a launch adds exactly (tiles of the slice) to each it
-    // uses, and the host keeps the running bases (pt_ctx::tile_base).
-    unsigned int *tile_ctr;            // MAX_SLICES counters, TILE_CTR_STRIDE apart
-    unsigned int tile_base[MAX_SLICES];
+    // The drain gate (pt_trace_gate, include/pt.h): the workgroup of a trace launch that is dispatched LAST writes
+    // gate_value to *gate as it starts -- from then on the launch has no work left to hand out and its waves only
+    // finish, so a launch waiting for that value on another stream fills the slots they leave.  Null: no signal.
+    unsigned long long *gate;
+    unsigned long long gate_value;
     int      n_nodes;
     int      bvh_cache_nodes;          // trace_bvh_kernel: the first this many nodes (level order: the top of the tree) live in LDS
     int      bvh_depth;                // deepest leaf: the walk's stack holds at most this many far children
@@ -75,10 +73,9 @@ struct TraceArgs {
 // Launchers (pt_kernels.hip).  All return the hipError_t of the launch.
 // `scene_kernel`: trace_static_kernel compiled for this scene (jit_static_kernel), launched in place of the
 // general one where that would run; null: none.
-// `tile_base`: the context's running bases of TraceArgs::tile_ctr, advanced by what the launch adds to the counters.
 hipError_t launch_trace(const TraceArgs &a, const float4 *geom_host, bool reuse_primary,
                         bool has_specular, bool lds_tiles, bool steal, hipStream_t s,
-                        hipFunction_t scene_kernel = nullptr, unsigned int *tile_base = nullptr);
+                        hipFunction_t scene_kernel = nullptr);
 hipError_t launch_primary(const TraceArgs &a, int32_t *idx, double *t, double *normal, hipStream_t s);
 hipError_t launch_rgb8(const float *canvas, uint8_t *rgb, int H, int W, int mode,
                        double inv_samples, hipStream_t s);

@@ -293,6 +293,7 @@ __global__ __launch_bounds__(NS == -1 ? TILED_BLOCK : TRACE_BLOCK) void trace_ke
     };
 
     const int npix = a.height * a.width;
+    signal_gate(a);
     const int pixel = blockIdx.x * BLOCK + threadIdx.x;
     const bool in_canvas = pixel < npix;
     const int pc = in_canvas ? pixel : 0;
@@ -470,6 +471,7 @@ __global__ __launch_bounds__(NS == -2 ? 64 : TRACE_BLOCK) void trace_steal_kerne
     const int tid = threadIdx.x;
     const int wbase = tid & ~63;
     const int npix = a.height * a.width;
+    signal_gate(a);
     const int pixel0 = blockIdx.x * BLOCK;
     const bool in_canvas = pixel0 + tid < npix;
     const int pc = in_canvas ? pixel0 + tid : 0;
@@ -687,6 +689,7 @@ __global__ __launch_bounds__(BVH_BLOCK) void trace_bvh_kernel(TraceArgs a)
     const int tid = threadIdx.x;
     const int wbase = tid & ~63;                           // this wave's first slot in the per-pixel arrays
     const int npix = a.height * a.width;
+    signal_gate(a);
     const int pixel0 = blockIdx.x * BLOCK;
     const bool in_canvas = pixel0 + tid < npix;
     const int pc = in_canvas ? pixel0 + tid : 0;
@@ -975,7 +978,7 @@ __global__ __launch_bounds__(256) void slice_sum_kernel(float4 *__restrict__ can
 
 template <int NS>
 static hipError_t launch_trace_ns(TraceArgs a, const float4 *geom_host, bool reuse, bool spec, bool steal,
-                                  hipStream_t s, hipFunction_t scene_kernel = nullptr, unsigned int *tile_base = nullptr)
+                                  hipStream_t s, hipFunction_t scene_kernel = nullptr)
 {
     // pad the by-value object list to NS with records that never pass the
     // 0 < t < Inf guard (n = 0 gives t = NaN)
@@ -1008,15 +1011,7 @@ static hipError_t launch_trace_ns(TraceArgs a, const float4 *geom_host, bool reu
                 a.n_slices = 2;
                 a.slice_n[1] = n / 16; a.slice_n[0] = n - a.slice_n[1]; a.slice_j0[1] = a.slice_n[0];
             }
-            // PT_PERSIST=<workgroups> (experiment): keep the grid at that many one-wave workgroups per slice; each
-            // walks the tiles blockIdx.x, blockIdx.x + gridDim.x, ... (8192 = the waves the chip holds at 8 per SIMD)
-            static const unsigned persist = getenv("PT_PERSIST") ? (unsigned)atoi(getenv("PT_PERSIST")) : 0u;
-            unsigned gx = (unsigned)((npix + STATIC_BLOCK - 1) / STATIC_BLOCK);
-            const unsigned n_tiles = gx;
-            if (persist && a.tile_ctr && tile_base && gx > persist) gx = persist;
-            if (gx < n_tiles)                                  // persistent: every slice's counter advances by its tiles
-                for (int y = 0; y < a.n_slices; ++y) { a.tile_base[y] = tile_base[y]; tile_base[y] += n_tiles; }
-            const dim3 sgrid(gx, a.n_slices), sblock(STATIC_BLOCK);
+            const dim3 sgrid((npix + STATIC_BLOCK - 1) / STATIC_BLOCK, a.n_slices), sblock(STATIC_BLOCK);
             hipError_t e;
             if (!a.pix) return hipErrorInvalidValue;           // (trace_block allocates it or fails)
             if (!a.pix_valid) {                                // first launch of this camera and scene: the fp64 primary pass
@@ -1087,11 +1082,11 @@ static hipError_t launch_trace_ns(TraceArgs a, const float4 *geom_host, bool reu
 }
 
 hipError_t launch_trace(const TraceArgs &a, const float4 *geom_host, bool reuse, bool spec, bool lds_tiles,
-                        bool steal, hipStream_t s, hipFunction_t scene_kernel, unsigned int *tile_base)
+                        bool steal, hipStream_t s, hipFunction_t scene_kernel)
 {
-    if (a.n_obj <= 4) return launch_trace_ns<4>(a, geom_host, reuse, spec, steal, s, scene_kernel, tile_base);
+    if (a.n_obj <= 4) return launch_trace_ns<4>(a, geom_host, reuse, spec, steal, s, scene_kernel);
     if (a.n_obj <= MAX_STATIC_OBJECTS)
-        return launch_trace_ns<MAX_STATIC_OBJECTS>(a, geom_host, reuse, spec, steal, s, scene_kernel, tile_base);
+        return launch_trace_ns<MAX_STATIC_OBJECTS>(a, geom_host, reuse, spec, steal, s, scene_kernel);
     if (lds_tiles) return launch_trace_ns<-1>(a, geom_host, reuse, spec, false, s);
     if (a.n_nodes > 0) return launch_trace_ns<-2>(a, geom_host, reuse, spec, steal, s);
     return launch_trace_ns<0>(a, geom_host, reuse, spec, steal, s);

@@ -29,6 +29,13 @@ __device__ __forceinline__ unsigned long long *seg_lane(unsigned long long *base
     return base + (blockIdx.x & (SEG_LANES - 1)) * SEG_LANE_STRIDE;
 }
 
+// The drain gate (TraceArgs::gate): the last workgroup in dispatch order announces that the launch has started it.
+__device__ __forceinline__ void signal_gate(const TraceArgs &a)
+{
+    if (a.gate && blockIdx.x == gridDim.x - 1 && blockIdx.y == gridDim.y - 1 && threadIdx.x == 0)
+        __hip_atomic_store(a.gate, a.gate_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // the per-pixel fp64 primary segment, through the spatial index when the scene has one
 template <typename STK = int>
 __device__ __forceinline__ PrimaryHit primary_hit(const TraceArgs &a, int pi, int pj, STK *stack = nullptr, int stride = 0)
@@ -291,6 +298,7 @@ __global__ __launch_bounds__(STATIC_BLOCK) void trace_static_kernel(TraceArgs a,
     __shared__ float4   s_pix[BLOCK * RV];
     __shared__ float    s_acc[MASKS ? 1 : BLOCK * 3];   // (!MASKS) per pixel: radiance gathered in phase 2
     const int tid = threadIdx.x;
+    signal_gate(a);
     if (tid < 4 * R) {
         const int f = tid / R, r = tid - f * R;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -315,24 +323,10 @@ __global__ __launch_bounds__(STATIC_BLOCK) void trace_static_kernel(TraceArgs a,
     const int wbase = tid & ~63;
     const int npix = a.height * a.width;
     __syncthreads();                                       // s_mat is staged
-    // A workgroup (one wave) renders tiles of 64 adjacent pixels: tile blockIdx.x, and -- when the launcher keeps the
-    // grid below the number of tiles (a persistent launch: about as many waves as the chip holds) -- further tiles
-    // drawn from a counter until none is left, without leaving its wave slot.  The draw for the NEXT tile is issued
-    // at the start of this one and read at its end, so its latency is never waited for.
-    const int n_tiles = (npix + BLOCK - 1) / BLOCK;
-    const bool persistent = (int)gridDim.x < n_tiles;      // wave-uniform
-    unsigned long long wave_segs = 0;                      // lane 0: the wave's segment count over its tiles
-    for (int tile = blockIdx.x; tile < n_tiles;) {
-    unsigned int drawn = 0;
-    if (persistent && tid == 0) drawn = atomicAdd(a.tile_ctr + blockIdx.y * TILE_CTR_STRIDE, 1u);
-    // (the lane index through an opaque move, once per tile: addresses formed from it are then recomputed per tile
-    // instead of being carried -- as 64-bit per-lane induction pointers and hoisted invariants -- through the hot loop,
-    // which cost 14 VGPRs and the eighth wave per SIMD)
-    int ltid = tid;
-    asm volatile("" : "+v"(ltid));
-    const int pixel0 = tile * BLOCK;
-    const bool in_canvas = pixel0 + ltid < npix;
-    const int pc = in_canvas ? pixel0 + ltid : 0;
+    unsigned long long wave_segs = 0;                      // lane 0: the wave's segment count
+    const int pixel0 = blockIdx.x * BLOCK;
+    const bool in_canvas = pixel0 + tid < npix;
+    const int pc = in_canvas ? pixel0 + tid : 0;
     const uint32_t B = (uint32_t)a.max_bounces;
     const uint32_t Bm1 = B - 1u;                    // 1 <= maxBounces (pt_create): the depth cap as one compare
     const uint32_t stride = a.sample_stride;
@@ -370,13 +364,13 @@ __global__ __launch_bounds__(STATIC_BLOCK) void trace_static_kernel(TraceArgs a,
             traced = false;
         }
     }
-    s_pix[ltid * RV + 0] = make_float4(cP0.x, cP0.y, cP0.z, __int_as_float(cidxp));
-    s_pix[ltid * RV + 1] = make_float4(ccol.x, ccol.y, ccol.z, ce);
-    s_pix[ltid * RV + 2] = make_float4(cd0.x, cd0.y, cd0.z, 0.f);
+    s_pix[tid * RV + 0] = make_float4(cP0.x, cP0.y, cP0.z, __int_as_float(cidxp));
+    s_pix[tid * RV + 1] = make_float4(ccol.x, ccol.y, ccol.z, ce);
+    s_pix[tid * RV + 2] = make_float4(cd0.x, cd0.y, cd0.z, 0.f);
     // LDS byte address of the current pixel's restart record (MASKS: read under exec at every restart, so that
     // the seven constants do not occupy registers through the loop -- 8 waves per SIMD instead of 7)
     const uint32_t rbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)&s_pix[0];
-    uint32_t raddr = rbase + (uint32_t)ltid * (RV * 16);
+    uint32_t raddr = rbase + (uint32_t)tid * (RV * 16);
 
     uint32_t pre_hi, pre_lo;                               // Philox's first product M * pixel, hoisted out of the loop
     {
@@ -552,9 +546,9 @@ __global__ __launch_bounds__(STATIC_BLOCK) void trace_static_kernel(TraceArgs a,
         //             have unstarted samples -- a pixel v, draw from its counter, hand what they gathered to their
         //             old pixel's record ([3].xyz, ds_add_f32) and point raddr at v's record; Philox's pixel product
         //             and the primary-object masks of the movers are wave-uniform values (one pixel), set from SGPRs.
-        const uint32_t own = rbase + (uint32_t)ltid * (RV * 16);
+        const uint32_t own = rbase + (uint32_t)tid * (RV * 16);
         lds_write_u32(own + 44, alive ? (ctr >> 6) + stride : gs_end);
-        s_pix[ltid * RV + 3] = make_float4(0.f, 0.f, 0.f, 0.f);
+        s_pix[tid * RV + 3] = make_float4(0.f, 0.f, 0.f, 0.f);
         unsigned long long alive_m = __builtin_amdgcn_ballot_w64(alive);
         thr = mk3(alive ? thr.x : 0.f, alive ? thr.y : 0.f, alive ? thr.z : 0.f);
         const uint32_t stride_v = to_vgpr(stride);
@@ -634,10 +628,10 @@ __global__ __launch_bounds__(STATIC_BLOCK) void trace_static_kernel(TraceArgs a,
                          : : [ra] "v"(raddr), [ax] "v"(acc.x), [ay] "v"(acc.y), [az] "v"(acc.z) : "memory");
         }
     } else {
-        s_next[ltid] = alive ? (ctr >> 6) + stride : gs_end;
-        s_acc[ltid * 3 + 0] = 0.f; s_acc[ltid * 3 + 1] = 0.f; s_acc[ltid * 3 + 2] = 0.f;
+        s_next[tid] = alive ? (ctr >> 6) + stride : gs_end;
+        s_acc[tid * 3 + 0] = 0.f; s_acc[tid * 3 + 1] = 0.f; s_acc[tid * 3 + 2] = 0.f;
         __syncthreads();
-        int cur = ltid;                                         // the pixel (workgroup-relative) this lane works on
+        int cur = tid;                                         // the pixel (workgroup-relative) this lane works on
         bool dry = false;                                      // wave-uniform: no pixel has an unstarted sample
         if (__ballot(alive) != 0ull || !dry) do {
             trip(false_type{}, [&](bool &terminal, uint32_t &c1, uint32_t &c1r) {
@@ -648,7 +642,7 @@ __global__ __launch_bounds__(STATIC_BLOCK) void trace_static_kernel(TraceArgs a,
                 const bool adopting = !dry && __ballot(needy) != 0ull;
                 while (!dry && __ballot(needy) != 0ull) {
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-                    const bool has = __hip_atomic_load(&s_next[ltid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < gs_end;
+                    const bool has = __hip_atomic_load(&s_next[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < gs_end;
                     const unsigned long long avail = __ballot(has);      // pixels of this wave with unstarted samples
                     if (avail == 0ull) { dry = true; break; }
                     const int v = wbase + (__ffsll((long long)avail) - 1);   // wave-uniform choice of pixel to help
@@ -693,19 +687,15 @@ __global__ __launch_bounds__(STATIC_BLOCK) void trace_static_kernel(TraceArgs a,
     __syncthreads();
     if (in_canvas) {
         if constexpr (MASKS) {
-            const float4 q = s_pix[ltid * RV + 3];
+            const float4 q = s_pix[tid * RV + 3];
             canvas[3 * (size_t)pc + 0] = q.x;
             canvas[3 * (size_t)pc + 1] = q.y;
             canvas[3 * (size_t)pc + 2] = q.z;
         } else {
-            canvas[3 * (size_t)pc + 0] = s_acc[ltid * 3 + 0];
-            canvas[3 * (size_t)pc + 1] = s_acc[ltid * 3 + 1];
-            canvas[3 * (size_t)pc + 2] = s_acc[ltid * 3 + 2];
+            canvas[3 * (size_t)pc + 0] = s_acc[tid * 3 + 0];
+            canvas[3 * (size_t)pc + 1] = s_acc[tid * 3 + 1];
+            canvas[3 * (size_t)pc + 2] = s_acc[tid * 3 + 2];
         }
-    }
-    __syncthreads();                                       // the records are free for the next tile
-    if (!persistent) break;
-    tile = (int)gridDim.x + (int)((unsigned int)__builtin_amdgcn_readfirstlane((int)drawn) - a.tile_base[blockIdx.y]);
     }
     // one global atomic per workgroup for the segment counter: 32,400 same-address
     // atomics (one per wave) serialise in L2 when a short launch's workgroups

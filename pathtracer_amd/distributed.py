@@ -118,7 +118,7 @@ class PipelinedFrames:
     (canvas_tensor); rgb: as many device uint8 buffers (rank 0 only, else None).
     """
 
-    def __init__(self, renderers, canvases, rgb, *, rank, spp_total, my_spp, mode, dist=None, allreduce=None):
+    def __init__(self, renderers, canvases, rgb, *, rank, spp_total, my_spp, mode, dist=None, allreduce=None, gate=False):
         """allreduce(renderer, canvas): queues the frame's ONE collective after the trace on the current
         stream and returns None (libpt's own ncclAllReduce, Renderer.allreduce_sum: it runs on the context's
         stream and the output kernel then reads the context's total) or a work handle to wait on
@@ -153,6 +153,11 @@ class PipelinedFrames:
             r.set_stream(m.cuda_stream)
         self.done = [None] * self.depth   # event: canvas k % depth is free again
         self.k = 0
+        # gate: frame k+1's trace starts when frame k's trace launch has dispatched its last workgroup (pt_trace_gate),
+        # i.e. exactly when wave slots begin to fall free, instead of whenever its canvas is free.  Measured
+        # (profiles/r03_frame_pipeline.txt): consecutive trace kernels then overlap by 380 instead of 160-190 us, and the
+        # step takes the same time -- the frame that waits is the one after, behind the starved collective.  Off by default.
+        self.gate = gate
 
     def step(self):
         torch = self.torch
@@ -161,6 +166,8 @@ class PipelinedFrames:
         with torch.cuda.stream(main):
             if self.done[b] is not None:
                 main.wait_event(self.done[b])                # frame k-depth's output has left this canvas
+            if self.gate and self.k > 0:
+                self.gate = r.trace_gate(self.r[(self.k - 1) % self.depth])
             r.reset()
             r.trace(self.my_spp)
             work = None

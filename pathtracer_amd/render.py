@@ -142,6 +142,15 @@ class Renderer:
     def set_stream(self, hip_stream: int):
         check(lib.pt_set_stream(self._ctx, C.c_void_p(hip_stream)), self._ctx)
 
+    def trace_gate(self, after: "Renderer") -> bool:
+        """pt_trace_gate: what is queued on this context's stream next waits until `after`'s most recent trace launch
+        has dispatched its last workgroup (it only drains from then on).  False where the device cannot do it."""
+        s = lib.pt_trace_gate(self._ctx, after._ctx)
+        if s == _lib.PT_ERR_UNSUPPORTED:
+            return False
+        check(s, self._ctx)
+        return True
+
     def rgb8_device(self, d_out: int, mode: int = _lib.PT_RGB8_REFERENCE, samples: int = 0):
         check(lib.pt_rgb8_device(self._ctx, C.c_void_p(d_out), mode, samples), self._ctx)
 

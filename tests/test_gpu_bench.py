@@ -37,8 +37,8 @@ def test_one_gpu_line_and_two_rank_rehearsal():
     two = _bench(["--gpus", "2", "--collective", "libpt"] + SMALL, {"PT_BENCH_REHEARSE_ONE_GPU": "1"})
     cfg = two["config"]
     assert two["n_gpus"] == 2 and "REHEARSAL" in cfg["collective"] and "libpt ncclAllReduce" in cfg["collective"]
-    # libpt's collective sat in the two-rank loop: one communicator (of one rank, on this one-GPU box) per rank
-    # process, shared by the rank's two pipelined contexts
+    # libpt's collective sat in the two-rank loop: communicators of one rank (on this one-GPU box), one per pipelined
+    # context of each rank process
     assert len(cfg["comm_info_per_context"]) == 2
     assert all(ci["n_ranks"] == 1 and ci["rccl_version"] > 0 for ci in cfg["comm_info_per_context"])
     assert len(cfg["per_rank_ms_per_step"]["all"]) == 2

@@ -11,8 +11,8 @@ import oracle as O
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("depth", [2, 3])
-def test_pipelined_frames_equal_inline_frames(depth):
+@pytest.mark.parametrize("depth,gate", [(2, False), (3, False), (2, True), (3, True)])
+def test_pipelined_frames_equal_inline_frames(depth, gate):
     import torch
     import pathtracer_amd as pa
     from pathtracer_amd.distributed import PipelinedFrames, canvas_tensor
@@ -31,7 +31,8 @@ def test_pipelined_frames_equal_inline_frames(depth):
         rs = [pa.Renderer(P, seed=3) for _ in range(depth)]      # frames in flight: canvases and trace streams
         cvs = [canvas_tensor(q, 0) for q in rs]
         rgbs = [torch.zeros(H * W * 3, dtype=torch.uint8, device="cuda") for _ in rs]
-        pipe = PipelinedFrames(rs, cvs, rgbs, rank=0, spp_total=SPP, my_spp=SPP, mode=pa.PT_RGB8_MEAN_CLAMP, dist=None)
+        pipe = PipelinedFrames(rs, cvs, rgbs, rank=0, spp_total=SPP, my_spp=SPP, mode=pa.PT_RGB8_MEAN_CLAMP, dist=None,
+                               gate=gate)
         assert pipe.depth == depth and len(pipe.mains) == depth
         seen = []
         for k in range(7):
@@ -42,6 +43,7 @@ def test_pipelined_frames_equal_inline_frames(depth):
                 seen.append(rgbs[prev].cpu().numpy().reshape(W, H, 3).copy())
         pipe.drain()
         seen.append(rgbs[b].cpu().numpy().reshape(W, H, 3).copy())
+        assert pipe.gate == gate                           # (pt_trace_gate is available on this device)
         for q in rs:
             q.close()
     assert len(seen) == 7
@@ -115,3 +117,34 @@ def test_rgb8_on_stream_needs_a_traced_canvas():
         r.rgb8_device_on(out.data_ptr(), s.cuda_stream)
         s.synchronize()
         assert np.array_equal(out.cpu().numpy().reshape(32, 32, 3), r.read_rgb8())
+
+
+def test_trace_gate_opens_before_the_gating_launch_ends():
+    """pt_trace_gate: a kernel queued behind the gate on another stream starts while the gating trace launch is still
+    running (its last workgroup has been dispatched, its waves are finishing), not after it."""
+    import torch
+    import pathtracer_amd as pa
+    P = pa.Params(1920, 1080, 500.0, 64, 8)
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    with pa.Renderer(P, seed=1) as a, pa.Renderer(pa.Params(64, 64, 500.0, 1, 4), seed=1) as b:
+        a.set_stream(sa.cuda_stream); b.set_stream(sb.cuda_stream)
+        assert b.trace_gate(a)                             # nothing traced on `a` yet: no wait, still supported
+        a.trace(64); a.synchronize()                       # warm-up: the fp64 primary pass, code objects
+        b.trace(1); b.synchronize()
+        best = None
+        for _ in range(5):
+            ends, started = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t0 = torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            t0.record(sa)
+            a.trace(64)                                    # ~1 ms of trace kernel on stream sa
+            ends.record(sa)
+            assert b.trace_gate(a)
+            started.record(sb)                             # behind the gate on stream sb
+            torch.cuda.synchronize()
+            lead = t0.elapsed_time(ends) - t0.elapsed_time(started)
+            best = lead if best is None else max(best, lead)
+        assert best > 0.02, f"the gate opened {best:.3f} ms before the launch ended"
+    with pa.Renderer(pa.Params(32, 32, 500.0, 1, 4)) as r:
+        with pytest.raises(pa.PtError):
+            r.trace_gate(r)
