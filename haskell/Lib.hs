@@ -16,8 +16,9 @@ module Lib
   , traces
   ) where
 
-import           Control.Concurrent.MVar (MVar, modifyMVar, newMVar)
+import           Control.Concurrent.MVar (MVar, newMVar, withMVar)
 import           Control.Monad          (when)
+import           Data.IORef             (IORef, newIORef, readIORef, writeIORef)
 import           Data.Array.Repa        ((:.) (..), Array, D, DIM3, Z (..))
 import qualified Data.Array.Repa        as R
 import qualified Data.Vector            as V
@@ -26,7 +27,7 @@ import           Data.Word              (Word32)
 import           Foreign
 import           Foreign.C.String       (CString, peekCString)
 import           Foreign.C.Types
-import           System.IO.Unsafe       (unsafePerformIO)
+import           System.IO.Unsafe       (unsafeDupablePerformIO, unsafePerformIO)
 
 import           LibPure                (bounceRay, reflectVector, specular)
 import           Object                 (Color (..), Form (..), Object (..), Point (..), Vector (..), objects)
@@ -107,39 +108,70 @@ context = unsafePerformIO $ alloca $ \pp -> with params $ \ppar -> do
 canvasLen :: Int
 canvasLen = Params.height * Params.width * 3
 
--- ONE host buffer for the whole process, and the index of the element of `traces` it holds (-1: none yet).
--- `traces` is a CAF and app/Web.hs:43 walks it for as long as the server runs, so an element must not own
--- memory: a buffer per element would grow by H*W*3 doubles per frame served (6 MB at 500x500), for ever.
-{-# NOINLINE slot #-}
-slot :: MVar (Int, ForeignPtr Double)
-slot = unsafePerformIO $ do
-  fp <- mallocForeignPtrArray canvasLen
-  newMVar (-1, fp)
+-- ONE host buffer for the whole process.  `traces` is a CAF and app/Web.hs:43 walks it for as long as the
+-- server runs, so an element must not own memory: a buffer per element would grow by H*W*3 doubles per frame
+-- served (6 MB at 500x500), for ever.
+{-# NOINLINE buffer #-}
+buffer :: ForeignPtr Double
+buffer = unsafePerformIO (mallocForeignPtrArray canvasLen)
 
--- The buffer, holding element k.  Rendered on demand: forwards with the pt_trace calls not made yet (so the
--- consecutive elements app/Web.hs pulls cost one traceCanvas each, and `traces !! numIters` of app/Write.hs:28
--- costs ONE pt_trace numIters and ONE read), backwards -- an element older than the buffer's is asked for
--- again -- with pt_reset and k fresh samples.  The random stream is keyed by (pixel, sample index, bounce),
--- so element k holds the same numbers whenever it is rendered (up to fp32 summation order; bit for bit with
--- PT_FLAG_NO_STEAL): the list stays a value.
-fetch :: Int -> IO (ForeignPtr Double)
-fetch k = modifyMVar slot $ \(have, fp) ->
-  if have == k
-    then return ((have, fp), fp)
-    else withForeignPtr context $ \ctx -> do
-      done <- alloca $ \pd -> do
-        c_pt_samples_done ctx pd >>= check ctx
-        fromIntegral <$> (peek pd :: IO Int64)
-      from <- if k < done then c_pt_reset ctx >>= check ctx >> return 0 else return done
-      when (k > from) $ c_pt_trace ctx (fromIntegral (k - from)) >>= check ctx
-      withForeignPtr fp $ \buf -> c_pt_read_sum ctx buf >>= check ctx
-      return ((k, fp), fp)
+-- Which element of `traces` the buffer holds (-1: none, or being refilled), and a stamp that changes whenever
+-- the buffer is about to change and again when it has changed: readers that find the same stamp before and
+-- after a read know the buffer was not touched in between.
+{-# NOINLINE held #-}
+held :: IORef (Int, Int)
+held = unsafePerformIO (newIORef (-1, 0))
+
+-- Serialises everything that talks to the library or refills the buffer (a pt_ctx is not thread-safe).
+{-# NOINLINE lock #-}
+lock :: MVar ()
+lock = unsafePerformIO (newMVar ())
+
+-- Under `lock`: make the buffer hold element k.  Rendered on demand: forwards with the pt_trace calls not made
+-- yet (so the consecutive elements app/Web.hs pulls cost one traceCanvas each, and `traces !! numIters` of
+-- app/Write.hs:28 costs ONE pt_trace numIters and ONE read), backwards -- an element older than the buffer's is
+-- asked for again -- with pt_reset and k fresh samples.  The random stream is keyed by (pixel, sample index,
+-- bounce), so element k holds the same numbers whenever it is rendered (up to fp32 summation order; bit for bit
+-- with PT_FLAG_NO_STEAL): the list stays a value.
+fetch :: Int -> IO ()
+fetch k = do
+  (have, stamp) <- readIORef held
+  when (have /= k) $ withForeignPtr context $ \ctx -> do
+    writeIORef held (-1, stamp + 1)
+    done <- alloca $ \pd -> do
+      c_pt_samples_done ctx pd >>= check ctx
+      fromIntegral <$> (peek pd :: IO Int64)
+    from <- if k < done then c_pt_reset ctx >>= check ctx >> return 0 else return done
+    when (k > from) $ c_pt_trace ctx (fromIntegral (k - from)) >>= check ctx
+    withForeignPtr buffer $ \buf -> c_pt_read_sum ctx buf >>= check ctx
+    writeIORef held (k, stamp + 2)
+
+-- Value i of element k, the slow way: under the lock, fetch and read (so no other thread can refill the buffer
+-- between the two).
+readLocked :: Int -> Int -> IO Double
+readLocked k i = withMVar lock $ \_ -> do
+  fetch k
+  withForeignPtr buffer $ \buf -> peekElemOff buf i
+
+-- Value i of element k.  While the buffer holds element k -- every index of app/Write.hs's `traces !! numIters`
+-- and of each frame app/Web.hs serves, but the first -- a read is two IORef reads around one peek and takes no
+-- lock: 6.2 M indices per 1080p element would otherwise each pay an MVar round trip.  A stamp that moved means
+-- another thread refilled the buffer meanwhile (two elements read at the same time); the slow path then gives
+-- the right value.  Elements read INTERLEAVED (R.zipWith over traces !! a and traces !! b) are correct but
+-- re-rendered at every switch -- copy one first (R.computeS).
+readAt :: Int -> Int -> IO Double
+readAt k i = do
+  (h1, s1) <- readIORef held
+  if h1 /= k
+    then readLocked k i
+    else do
+      x <- withForeignPtr buffer $ \buf -> peekElemOff buf i
+      (_, s2) <- readIORef held
+      if s1 == s2 then return x else readLocked k i
 
 -- Element k of `traces`: a delayed array that holds nothing but k.
 element :: Int -> Array D DIM3 Double
-element k = R.fromFunction sh $ \ix -> unsafePerformIO $ do
-  fp <- fetch k
-  withForeignPtr fp $ \buf -> peekElemOff buf (R.toIndex sh ix)
+element k = R.fromFunction sh $ \ix -> unsafeDupablePerformIO (readAt k (R.toIndex sh ix))
   where
     sh = Z :. Params.height :. Params.width :. 3
 

@@ -478,21 +478,28 @@ static void draw2(draw_state *d, double *u1, double *u2)
 
 /* terminalColor (src/Lib.hs:67-79) as a loop; bounceRay/reflectVector
  * (src/Lib.hs:101-113) inline.  Returns radiance of one sample. */
+/* `forced` (test aid, not a reference semantic; NULL in every reference-faithful entry point): the outcome of the
+ * FIRST closestObjectTo and march -- the struck object's index (or -1) and the hit point -- supplied by the caller
+ * instead of computed, and not counted in *segs.  o_trace_pixels_from_primary uses it. */
+typedef struct { int idx; o_vec3 hit; } forced_primary;
+
 static o_vec3 terminal_color(const o_params *p, const o_object *objs, int n,
-                             o_vec3 origin, o_vec3 vector, draw_state *d, uint64_t *segs)
+                             o_vec3 origin, o_vec3 vector, draw_state *d, uint64_t *segs,
+                             const forced_primary *forced)
 {
     o_vec3 black = { 0, 0, 0 };
     o_vec3 pixel = { 1, 1, 1 };          /* white, src/Lib.hs:64 */
     int last = -1;
     for (int left = p->max_bounces; left > 0; --left) {
-        double t;
-        ++*segs;
-        int k = o_closest_object_to(objs, n, origin, vector, last, &t);
+        double t = 0.0;
+        int k;
+        if (forced && left == p->max_bounces) k = forced->idx;
+        else { ++*segs; k = o_closest_object_to(objs, n, origin, vector, last, &t); }
         if (k < 0) return black;                                    /* :72 */
         const o_object *o = &objs[k];
         if (o->emittance > 0.0) return vscale(o->emittance, pixel); /* :74 */
         /* bounceRay (:101-106) */
-        o_vec3 hit = o_march(origin, vector, t);
+        o_vec3 hit = (forced && left == p->max_bounces) ? forced->hit : o_march(origin, vector, t);
         double u1, u2;
         draw2(d, &u1, &u2);
         o_vec3 nrm = o_normal_at(o, hit);
@@ -527,7 +534,7 @@ void o_trace(const o_params *p, const o_object *objs, int n,
                 d.pixel = (uint32_t)px; d.seed = p->seed;
                 d.sample = (uint64_t)(s_begin + it * stride); d.bounce = 0;
                 uint64_t segs = 0;
-                o_vec3 c = terminal_color(p, objs, n, zero, dir, &d, &segs);
+                o_vec3 c = terminal_color(p, objs, n, zero, dir, &d, &segs, 0);
                 total += segs;
                 sum[px * 3 + 0] += c.x; sum[px * 3 + 1] += c.y; sum[px * 3 + 2] += c.z; /* :65 */
                 if (sumsq) {
@@ -564,12 +571,52 @@ void o_trace_pixels(const o_params *p, const o_object *objs, int n, const int32_
             d.pixel = (uint32_t)px; d.seed = p->seed;
             d.sample = (uint64_t)(s_begin + it * stride); d.bounce = 0;
             uint64_t segs = 0;
-            o_vec3 c = terminal_color(p, objs, n, zero, dir, &d, &segs);
+            o_vec3 c = terminal_color(p, objs, n, zero, dir, &d, &segs, 0);
             total += segs;
             sum[q * 3 + 0] += c.x; sum[q * 3 + 1] += c.y; sum[q * 3 + 2] += c.z;
             if (sumsq) {
                 sumsq[q * 3 + 0] += c.x * c.x; sumsq[q * 3 + 1] += c.y * c.y; sumsq[q * 3 + 2] += c.z * c.z;
             }
+        }
+    }
+    if (segments) *segments += total;
+    (void)threads;
+}
+
+/* TEST AID, no counterpart in the reference: o_trace_pixels on the Philox stream with every listed pixel's primary
+ * segment SUPPLIED -- idx[q] the struck object (-1: none), point[3q..] the hit point, dir[3q..] the primary
+ * direction -- instead of computed by rayFromCamToPixel + closestObjectTo + march.  The device computes that segment
+ * once per pixel in fp64 and then carries point and direction in fp32; on the analytic tie lines of the default
+ * scene the hit point lies on two planes at once and whether the first bounce "sees" the second plane
+ * is decided by the last bit of that point, so a path-wise comparison there needs both sides to start from the very
+ * same numbers.  Everything from the first bounce on is terminal_color's fp64 arithmetic, unchanged.  The supplied
+ * segment is not counted in *segments. */
+void o_trace_pixels_from_primary(const o_params *p, const o_object *objs, int n, const int32_t *pixels, int64_t count,
+                                 const int32_t *idx, const double *point, const double *dir,
+                                 int64_t s_begin, int64_t iters, int64_t stride,
+                                 double *sum, uint64_t *segments, int threads)
+{
+    uint64_t total = 0;
+    if (stride < 1) stride = 1;
+#ifdef _OPENMP
+    if (threads < 1) threads = 1;
+#pragma omp parallel for schedule(dynamic, 16) num_threads(threads) reduction(+:total)
+#endif
+    for (int64_t q = 0; q < count; ++q) {
+        forced_primary f;
+        f.idx = idx[q];
+        f.hit.x = point[3 * q]; f.hit.y = point[3 * q + 1]; f.hit.z = point[3 * q + 2];
+        o_vec3 zero = { 0, 0, 0 };
+        o_vec3 d0 = { dir[3 * q], dir[3 * q + 1], dir[3 * q + 2] };
+        for (int64_t it = 0; it < iters; ++it) {
+            draw_state d;
+            d.mode = O_RNG_PHILOX; d.gen = 0;
+            d.pixel = (uint32_t)pixels[q]; d.seed = p->seed;
+            d.sample = (uint64_t)(s_begin + it * stride); d.bounce = 0;
+            uint64_t segs = 0;
+            o_vec3 c = terminal_color(p, objs, n, zero, d0, &d, &segs, &f);
+            total += segs;
+            sum[q * 3 + 0] += c.x; sum[q * 3 + 1] += c.y; sum[q * 3 + 2] += c.z;
         }
     }
     if (segments) *segments += total;

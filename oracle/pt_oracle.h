@@ -142,6 +142,15 @@ void o_trace_pixels(const o_params *p, const o_object *objs, int n, const int32_
                     o_stdgen *gens, int64_t s_begin, int64_t iters, int64_t sample_stride,
                     double *sum, double *sumsq, uint64_t *segments, int threads);
 
+/* TEST AID (no counterpart in the reference): o_trace_pixels on the Philox stream with each listed pixel's primary
+ * segment supplied by the caller -- idx[q] (struck object or -1), point[3q..] (hit point), dir[3q..] (primary
+ * direction) -- so that a path-wise comparison with the device can start from the device's own fp32-rounded hit
+ * point (the analytic tie lines).  The supplied segment is not counted in *segments. */
+void o_trace_pixels_from_primary(const o_params *p, const o_object *objs, int n, const int32_t *pixels, int64_t count,
+                                 const int32_t *idx, const double *point, const double *dir,
+                                 int64_t s_begin, int64_t iters, int64_t sample_stride,
+                                 double *sum, uint64_t *segments, int threads);
+
 /* ---- Conversion.hs ------------------------------------------------------ */
 /* listToPixelRGB8 (src/Conversion.hs:17-20): round-half-even of 255*x, then
  * Int -> Word8 wrap. */

@@ -35,13 +35,26 @@ if stats:
         if kern in row["Name"]:
             avg_ms = float(row["AverageNs"]) / 1e6
             calls = int(row["Calls"])
+# the same launches without the process's first one (cold: code-object load, clocks ramping up), from the trace itself
+warm_ms = None
+for f in glob.glob(os.path.join(src, "trace", "*", "*_kernel_trace.csv")):
+    durs = [(int(r["Start_Timestamp"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
+            for r in csv.DictReader(open(f)) if kern in r["Kernel_Name"]]
+    durs.sort()
+    if len(durs) > 1:
+        warm = [d for _, d in durs[1:]]
+        warm_ms = sum(warm) / len(warm)
+        first_ms = durs[0][1]
 lines.append("")
 lines.append("# derived")
-SEGS = 6551632325      # segments of one 1080p / 1024-spp / depth-8 frame of the default scene, seed 0 (pt_segments)
+SEGS = 6549558725      # segments of one 1080p / 1024-spp / depth-8 frame of the default scene, seed 0 (pt_segments)
 if avg_ms:
     lines.append(f"kernel-trace average duration: {avg_ms:.3f} ms over {calls} calls")
     lines.append(f"algorithmic rate: 97 flop x {SEGS} segments / {avg_ms:.3f} ms = {97 * SEGS / avg_ms / 1e9:.2f} TFLOP/s = "
                  f"{97 * SEGS / avg_ms / 1e9 / 157.3:.4f} of 157.3")
+    if warm_ms:
+        lines.append(f"warm launches only (without the process's first, {first_ms:.3f} ms): {warm_ms:.3f} ms -> "
+                     f"{97 * SEGS / warm_ms / 1e9 / 157.3:.4f} of 157.3")
 g = C.get
 if g("SQ_INSTS_VALU"):
     lines.append(f"VALU wave-instructions per segment-trip (64 lanes): {g('SQ_INSTS_VALU') / (SEGS / 64):.1f}")

@@ -54,7 +54,30 @@ def crops(H, W, depth, bounces, spp, name, threads=8):
     np.savez_compressed(os.path.join(HERE, name), H=H, W=W, camera_depth=depth, bounces=bounces, spp=spp, **out)
 
 
+def spot_pixels(H, W, count, seed):
+    """The spot set of tests/test_gpu_fullsize.py::_spot_check_scene: `count` random pixels plus corners and wave edges."""
+    rng = np.random.default_rng(seed)
+    return np.unique(np.concatenate([rng.integers(0, H * W, count),
+                                     [0, W - 1, (H - 1) * W, H * W - 1, 63, 64, 255, 256, H * W - 65]])).astype(np.int32)
+
+
+def config5_spots(name, count=64, seed=46, threads=8):
+    """BASELINE.json configs[4] as written -- 10,000 disks (libpt's generator, SplitMix64 seed 2), 3840x2160, 4096 spp,
+    depth 16 -- at `count` spot pixels on the device's Philox stream (seed 1): about a minute of CPU per pixel (the
+    oracle scans all 10,000 objects per segment, as closestObjectTo does), so the sums are a fixture."""
+    import pathtracer_amd as pa
+    H, W, spp, bounces = 3840, 2160, 4096, 16
+    objs = pa.synthetic_scene(10000, 2, "disks")
+    px = spot_pixels(H, W, count, seed)
+    s, segs = O.trace_pixels(O.params(H, W, 500.0, bounces, O.PHILOX, 1), O.scene_from(objs), px, spp, threads=threads)
+    np.savez_compressed(os.path.join(HERE, name), pixels=px, sum=s, segments=segs, H=H, W=W, camera_depth=500.0,
+                        bounces=bounces, spp=spp, philox_seed=1, scene_objects=10000, scene_seed=2, scene_kind="disks")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "config5":      # (ten minutes on 8 cores; the rest takes about as long)
+        config5_spots("spots_config5_10000disks_3840x2160_4096spp_d16.npz")
+        sys.exit(0)
     crops(1920, 1080, 500.0, 8, 2048, "crops_stdgen_1920x1080_d8_2048spp.npz")
     primary(64, 64, 500.0, "primary_default_64x64.npz")
     primary(200, 200, 500.0, "primary_default_200x200.npz")

@@ -66,6 +66,9 @@ def _load():
         "o_trace_pixels": (None, [C.POINTER(OParams), C.POINTER(OObject), C.c_int, C.c_void_p, C.c_int64, C.c_void_p,
                                   C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64),
                                   C.c_int]),
+        "o_trace_pixels_from_primary": (None, [C.POINTER(OParams), C.POINTER(OObject), C.c_int, C.c_void_p, C.c_int64,
+                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64,
+                                               C.c_void_p, C.POINTER(C.c_uint64), C.c_int]),
         "o_to_word8": (C.c_uint8, [d]),
         "o_repa3_to_image": (None, [C.POINTER(OParams), C.c_void_p, C.c_void_p]),
     }
@@ -142,6 +145,34 @@ def trace_pixels(p, objs, pixels, iters, s_begin=0, stride=1, threads=8):
     L.o_trace_pixels(C.byref(p), objs, len(objs), pixels.ctypes.data, len(pixels), None, s_begin, iters, stride,
                      out.ctypes.data, None, C.byref(segs), threads)
     return out, segs.value
+
+
+def trace_pixels_from_primary(p, objs, pixels, idx, point, direction, iters, s_begin=0, stride=1, threads=8):
+    """Test aid (no reference semantic): trace_pixels with each listed pixel's primary segment supplied -- struck
+    object index (or -1), hit point and primary direction -- e.g. the device's own fp32-rounded numbers, so that both
+    sides start the first bounce from the same point (the analytic tie lines).  -> (sums, segments from the first
+    bounce on)."""
+    assert p.rng == PHILOX
+    pixels = np.ascontiguousarray(pixels, np.int32)
+    idx = np.ascontiguousarray(idx, np.int32)
+    point = np.ascontiguousarray(point, np.float64).reshape(-1, 3)
+    direction = np.ascontiguousarray(direction, np.float64).reshape(-1, 3)
+    assert len(idx) == len(pixels) == len(point) == len(direction)
+    out = np.zeros((len(pixels), 3), np.float64)
+    segs = C.c_uint64(0)
+    L.o_trace_pixels_from_primary(C.byref(p), objs, len(objs), pixels.ctypes.data, len(pixels), idx.ctypes.data,
+                                  point.ctypes.data, direction.ctypes.data, s_begin, iters, stride, out.ctypes.data,
+                                  C.byref(segs), threads)
+    return out, segs.value
+
+
+def primary_directions(p, pixels):
+    """rayFromCamToPixel's direction (src/Lib.hs:41-51) of the listed pixels (i*W + j): (len, 3) float64."""
+    out = np.zeros((len(pixels), 3), np.float64)
+    for q, px in enumerate(pixels):
+        v = L.o_primary_direction(C.byref(p), int(px) // p.width, int(px) % p.width)
+        out[q] = (v.x, v.y, v.z)
+    return out
 
 
 def trace_pixels_stdgen(p, objs, pixels, iters, threads=8):

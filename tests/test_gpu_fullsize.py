@@ -14,6 +14,8 @@ size-independent properties elsewhere.
   * the RGB8 image of the full canvas, byte for byte against the oracle's
     quantiser applied to the device's own sum.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -216,7 +218,9 @@ def test_rgb8_of_full_canvas(pa):
 # an hour per GPU), so it runs at its full image size, object count and depth with 256 spp (the spatial index makes that seconds;
 # the full 4096 spp would be about a minute and a half on one GPU).
 
-def _spot_check_scene(pa, H, W, objs, spp, bounces, cam, count, seed, chunk=None):
+def _spot_check_scene(pa, H, W, objs, spp, bounces, cam, count, seed, chunk=None, golden=None):
+    """golden: a fixture of tests/golden/make_golden.py holding the oracle's sums for this very spot set (where the
+    oracle is too slow to run inside the test)."""
     rng = np.random.default_rng(seed)
     px = np.unique(np.concatenate([rng.integers(0, H * W, count),
                                    [0, W - 1, (H - 1) * W, H * W - 1, 63, 64, 255, 256, H * W - 65]])).astype(np.int32)
@@ -227,7 +231,13 @@ def _spot_check_scene(pa, H, W, objs, spp, bounces, cam, count, seed, chunk=None
         assert r.samples_done == spp
         dev = r.read_sum().reshape(-1, 3)
         segs = r.segments
-    ora, _ = O.trace_pixels(O.params(H, W, cam, bounces, O.PHILOX, 1), O.scene_from(objs), px, spp, threads=16)
+    if golden is not None:
+        g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", golden))
+        assert np.array_equal(g["pixels"], px) and (int(g["H"]), int(g["W"]), int(g["spp"]), int(g["bounces"])) == (H, W, spp, bounces)
+        assert int(g["philox_seed"]) == 1 and float(g["camera_depth"]) == cam
+        ora = g["sum"]
+    else:
+        ora, _ = O.trace_pixels(O.params(H, W, cam, bounces, O.PHILOX, 1), O.scene_from(objs), px, spp, threads=16)
     d = dev[px]
     rel = np.abs(d - ora) / np.maximum(np.abs(ora), 1e-9)
     close = ((rel <= 1e-3) | (np.abs(d - ora) <= 1e-4)).all(axis=1)
@@ -253,9 +263,12 @@ def test_config5_ten_thousand_disks_full_image_reduced_spp(pa):
 def test_config5_as_written_4096_spp_depth_16_on_one_gpu(pa):
     """BASELINE.json configs[4] at its stated size -- 10,000 objects, 3840x2160, 4096 spp, depth 16 -- on ONE GPU
     (the configuration names 8; the sample split only divides these launches among ranks): 3.4e10 paths, about a
-    quarter of a minute of kernels, spot-checked against the oracle on the same Philox stream."""
+    quarter of a minute of kernels, spot-checked against the oracle on the same Philox stream at 73 pixels (64 random,
+    corners and wave edges).  The oracle scans all 10,000 objects per segment, about a minute of CPU per pixel, so its
+    sums are the committed fixture tests/golden/spots_config5_*.npz (make_golden.py config5)."""
     objs = pa.synthetic_scene(10000, 2, "disks")
-    segs = _spot_check_scene(pa, 3840, 2160, objs, 4096, 16, 500.0, 4, 46, chunk=256)
+    segs = _spot_check_scene(pa, 3840, 2160, objs, 4096, 16, 500.0, 64, 46, chunk=256,
+                             golden="spots_config5_10000disks_3840x2160_4096spp_d16.npz")
     assert segs > 3840 * 2160 * 4096
 
 

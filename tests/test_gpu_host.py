@@ -76,6 +76,22 @@ def test_haskell_shim_call_sequence_web(tmp_path):
     assert bad <= 0.01, bad
 
 
+def test_haskell_shim_interleaved_elements(tmp_path):
+    """Two elements read in turns (R.zipWith over traces !! 2 and traces !! 5: the one buffer flips at every switch,
+    forwards by pt_trace, backwards by pt_reset + fresh samples): every read returns its own element's numbers."""
+    H, W, B = 48, 40, 6
+    el = _replay(tmp_path, H, W, B, [2, 5, 2, 5, 5, 2])
+    assert np.array_equal(el[1], el[3]) and np.array_equal(el[1], el[4])
+    assert not np.array_equal(el[0], el[1])
+    # element 2 rendered as 2 fresh samples each time: the same numbers bit for bit
+    assert np.array_equal(el[0], el[2]) and np.array_equal(el[0], el[5])
+    ora = O.Tracer(O.params(H, W, 500.0, B, O.PHILOX, 0), O.default_scene(), threads=4)
+    two = ora.trace(2).copy()
+    five = ora.trace(3)
+    for got, want in ((el[0], two), (el[1], five)):
+        assert (np.abs(got - want) > 2e-4 * np.abs(want) + 1e-5).any(axis=2).mean() <= 0.01
+
+
 def test_haskell_shim_call_sequence_write(tmp_path):
     """app/Write.hs:28 is traces !! numIters: ONE pt_trace numIters and ONE read."""
     import pathtracer_amd as pa

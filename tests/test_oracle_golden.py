@@ -140,3 +140,17 @@ def test_pixel_subset_stdgen_equals_the_full_frame_tracer():
     s, sq, _ = O.trace_pixels_stdgen(p, O.default_scene(), px, spp, threads=2)
     assert np.array_equal(s, full.sum.reshape(-1, 3)[px])
     assert np.array_equal(sq, full.sumsq.reshape(-1, 3)[px])
+
+
+def test_from_primary_aid_reproduces_the_plain_trace():
+    """o_trace_pixels_from_primary (a test aid for the tie-line parity test) handed the oracle's OWN primary segment
+    must give the plain trace bit for bit, with exactly one search per path fewer counted."""
+    p = O.params(64, 64, 500.0, 6, O.PHILOX, 3)
+    objs = O.default_scene()
+    px = np.arange(0, 64 * 64, 37, dtype=np.int32)
+    plain, segs = O.trace_pixels(p, objs, px, 8)
+    idx, t, _ = O.primary_hits(p, objs)
+    d = O.primary_directions(p, px)
+    forced, segs_f = O.trace_pixels_from_primary(p, objs, px, idx.reshape(-1)[px], d * t.reshape(-1)[px][:, None], d, 8)
+    assert np.array_equal(plain, forced)
+    assert segs - segs_f == len(px) * 8
