@@ -34,6 +34,8 @@ def test_pipelined_frames_equal_inline_frames(depth, gate):
         pipe = PipelinedFrames(rs, cvs, rgbs, rank=0, spp_total=SPP, my_spp=SPP, mode=pa.PT_RGB8_MEAN_CLAMP, dist=None,
                                gate=gate)
         assert pipe.depth == depth and len(pipe.mains) == depth
+        # the guard against the round-1 hang (profiles/r03_priority_probe.txt): no stream of the loop has a priority
+        assert pipe.side.priority == 0 and all(m.priority == 0 for m in pipe.mains)
         seen = []
         for k in range(7):
             b = pipe.step()
