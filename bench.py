@@ -334,7 +334,7 @@ def main():
     # set-up, like the scene upload: the trace kernel compiled for this scene (pt_scene_specialise; by-value
     # scenes on the default flags only -- elsewhere, or without hiprtc on the machine, the general kernel stays)
     specialised = False
-    if not args.no_specialise and len(scene) <= 8 and not (args.no_steal or args.no_primary_reuse):
+    if not args.no_specialise and len(scene) <= 16 and not (args.no_steal or args.no_primary_reuse):
         specialised = all([q.specialise() for q in rs])
         if not specialised:
             print("bench.py: pt_scene_specialise unavailable: " + rs[0].last_error(), file=sys.stderr)

@@ -270,11 +270,16 @@ int pt_dev_philox(pt_ctx *ctx, int32_t n, const uint32_t *c0, const uint32_t *c1
  * are) are not computed.  The arithmetic that remains is the general kernel's
  * rounding for rounding: images agree bit for bit, except that a ray direction
  * with an exactly zero component may see -0 where the general form sees +0.
- * Costs a compilation (about a second; cached per process, scene and device --
- * a compiled kernel, ~16 KB, stays loaded until the process ends), so it is
- * meant for a scene that will be traced for a while.  Applies to scenes of
- * <= 8 objects on the default flags; the kernel is dropped by the next
- * pt_scene_upload.  On PT_ERR_UNSUPPORTED (no libhiprtc on the machine, a scene
+ * Costs a compilation (about a second) the first time a scene is seen: compiled
+ * kernels are shared by the contexts of a process (pt_jit_cache_size) and kept
+ * as files for later processes -- in $PT_KERNEL_CACHE, else
+ * $XDG_CACHE_HOME/pathtracer_amd, else $HOME/.cache/pathtracer_amd; each file
+ * spells out the kernel source, geometry, target and compiler it was built
+ * from and is used only if all of it matches; PT_KERNEL_CACHE=off disables
+ * the files.  Applies to scenes of <= 16 objects on the default flags (for 9-16
+ * objects, whose list the general path streams through the scalar cache, the
+ * scene kernel is the only by-value kernel: measured 2.3x the streamed rate);
+ * the kernel is dropped by the next pt_scene_upload.  On PT_ERR_UNSUPPORTED (no libhiprtc on the machine, a scene
  * or flags it does not cover) the context keeps using the general kernel.
  * PT_SPECIALISE=1 in the environment makes pt_scene_upload do this for every
  * scene it applies to (failures ignored). */

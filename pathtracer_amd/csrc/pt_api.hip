@@ -371,7 +371,8 @@ int pt_scene_upload(pt_ctx *c, const pt_object *objs, int32_t n)
     // PT_SPECIALISE=1 in the environment: pt_scene_specialise for every scene it applies to (how the whole GPU
     // test suite is run against the scene kernels); where it does not apply the general kernel stays, silently
     if (const char *e = getenv("PT_SPECIALISE")) {
-        if (e[0] == '1' && c->n_obj <= MAX_STATIC_OBJECTS && !(c->p.flags & (PT_FLAG_NO_STEAL | PT_FLAG_NO_PRIMARY_REUSE))) {
+        if (e[0] == '1' && c->n_obj <= MAX_JIT_OBJECTS &&
+            !(c->p.flags & (PT_FLAG_NO_STEAL | PT_FLAG_NO_PRIMARY_REUSE | PT_FLAG_LDS_TILES))) {
             std::string why;
             c->scene_kernel = jit_static_kernel(c->p.device, c->n_obj, c->has_specular, c->h_geom.data(), why);
         }
@@ -414,12 +415,14 @@ int pt::trace_block(pt_ctx *c, int64_t k_begin, int32_t iters)
 
     const bool reuse = !(c->p.flags & PT_FLAG_NO_PRIMARY_REUSE);
     // planes for the sample slices of trace_static_kernel (small scenes, default flags, large launches)
-    if (!c->d_partial && iters >= SLICE_MIN_SAMPLES && c->n_obj <= MAX_STATIC_OBJECTS && reuse && !(c->p.flags & PT_FLAG_NO_STEAL))
+    // the by-value kernels: up to 8 objects, and up to 16 where a kernel has been compiled for the scene
+    const bool static_path = (c->n_obj <= MAX_STATIC_OBJECTS || (c->scene_kernel && c->n_obj <= MAX_JIT_OBJECTS)) && reuse &&
+                             !(c->p.flags & PT_FLAG_NO_STEAL);
+    if (!c->d_partial && iters >= SLICE_MIN_SAMPLES && static_path)
         if (hipMalloc((void **)&c->d_partial, (size_t)(MAX_SLICES - 1) * npix(c) * 3 * sizeof(float)) != hipSuccess) {
             (void)hipGetLastError();                 // no memory for the planes: launches stay unsliced
             c->d_partial = nullptr;
         }
-    const bool static_path = c->n_obj <= MAX_STATIC_OBJECTS && reuse && !(c->p.flags & PT_FLAG_NO_STEAL);
     if (static_path && !c->d_pix) {                  // the kept primary hits, 32 B per pixel (primary_fill_kernel)
         const hipError_t e = hipMalloc((void **)&c->d_pix, npix(c) * 2 * sizeof(float4));
         if (e != hipSuccess) {
@@ -479,10 +482,10 @@ int pt_scene_specialise(pt_ctx *c)
     if (int s = check_ctx(c)) return s;
     if (c->group) return group_scene_specialise(c);
     if (!c->have_scene) return fail(c, PT_ERR_NO_SCENE, "pt_scene_specialise: no scene uploaded");
-    if (c->n_obj > MAX_STATIC_OBJECTS)
-        return fail(c, PT_ERR_UNSUPPORTED, "pt_scene_specialise: only scenes of <= 8 objects have a kernel to specialise");
-    if (c->p.flags & (PT_FLAG_NO_STEAL | PT_FLAG_NO_PRIMARY_REUSE))
-        return fail(c, PT_ERR_UNSUPPORTED, "pt_scene_specialise: the strict kernels are not specialised");
+    if (c->n_obj > MAX_JIT_OBJECTS)
+        return fail(c, PT_ERR_UNSUPPORTED, "pt_scene_specialise: only scenes of <= 16 objects have a kernel to specialise");
+    if (c->p.flags & (PT_FLAG_NO_STEAL | PT_FLAG_NO_PRIMARY_REUSE | PT_FLAG_LDS_TILES))
+        return fail(c, PT_ERR_UNSUPPORTED, "pt_scene_specialise: the strict and tiled kernels are not specialised");
     std::string why;
     hipFunction_t fn = jit_static_kernel(c->p.device, c->n_obj, c->has_specular, c->h_geom.data(), why);
     if (!fn) return fail(c, PT_ERR_UNSUPPORTED, "pt_scene_specialise: " + why + " (the general kernel stays in use)");

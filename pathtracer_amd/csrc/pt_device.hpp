@@ -55,6 +55,7 @@ constexpr int MAT_FLOATS = 16;
 constexpr int PRIM_DOUBLES = 19;     // centre 3, normal 3, unit normal 3, radius, kind, Rectangle: u 3, w 3, half width, half height
 
 constexpr int MAX_STATIC_OBJECTS = 8;
+constexpr int MAX_JIT_OBJECTS = 16;             // scenes of 9-16 objects have a by-value kernel only as a scene kernel (pt_jit.hip)
 
 struct f3 { float x, y, z; };
 

@@ -17,6 +17,8 @@
 #include "pt_internal.hpp"
 
 #include <dlfcn.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include <cstdio>
 #include <cstdlib>
@@ -53,8 +55,11 @@ Rtc &rtc()
     static Rtc r;
     static std::once_flag once;
     std::call_once(once, [] {
-        // PT_HIPRTC names the library file (experiments: one compiler against another in the same process)
+#ifdef PT_EXPERIMENTS
+        // PT_HIPRTC names the library file (experiments: one compiler against another in the same process).  Only in
+        // builds made with `make EXP=-DPT_EXPERIMENTS`: the shipped library opens no file the environment names.
         if (const char *forced = getenv("PT_HIPRTC")) r.lib = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
+#endif
         for (const char *name : {"libhiprtc.so", "libhiprtc.so.7", "/opt/rocm/lib/libhiprtc.so"}) {
             if (r.lib) break;
             r.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
@@ -79,6 +84,81 @@ Rtc &rtc()
         }
     });
     return r;
+}
+
+// ---- the on-disk cache of compiled scene kernels ---------------------------------------------------------------
+// A scene kernel takes hiprtc 0.4-0.9 s; a host that starts often with the same scene (app/Write.hs renders one image
+// per process, src/Object.hs:147-148 is a constant of the program) pays it every time.  Compiled code objects are
+// therefore kept as files: <dir>/<128-bit hash of everything the code depends on>.co, each starting with that
+// "everything" spelled out -- the kernel source text as embedded in this library, the scene's geometry bits, NS, SPEC,
+// the --offload-arch, the compiler options and the hiprtc that compiled it -- which is compared byte for byte
+// before the code is used, so a hash collision or a file of another build is a miss, not a wrong kernel.
+// <dir> = $PT_KERNEL_CACHE (empty, "0" or "off": no cache), else $XDG_CACHE_HOME/pathtracer_amd, else
+// $HOME/.cache/pathtracer_amd.  Best effort throughout: any failure to read or write is a miss / a skipped write.
+// The files are code this library will run: the directory must be writable by the user only (it is created 0700).
+std::string disk_cache_dir()
+{
+    if (const char *e = getenv("PT_KERNEL_CACHE")) {
+        const std::string v = e;
+        return (v.empty() || v == "0" || v == "off") ? std::string() : v;
+    }
+    if (const char *x = getenv("XDG_CACHE_HOME")) if (*x) return std::string(x) + "/pathtracer_amd";
+    if (const char *h = getenv("HOME")) if (*h) return std::string(h) + "/.cache/pathtracer_amd";
+    return std::string();
+}
+
+std::string disk_cache_name(const std::string &material)
+{
+    uint64_t a = 0xcbf29ce484222325ull, b = 0x84222325cbf29ce4ull;      // two FNV-1a streams, the second over the reversed text
+    for (size_t i = 0; i < material.size(); ++i) {
+        a = (a ^ (unsigned char)material[i]) * 0x100000001b3ull;
+        b = (b ^ (unsigned char)material[material.size() - 1 - i]) * 0x100000001b3ull;
+    }
+    char buf[40];
+    std::snprintf(buf, sizeof buf, "%016llx%016llx.co", (unsigned long long)a, (unsigned long long)b);
+    return buf;
+}
+
+constexpr char DISK_MAGIC[8] = {'P', 'T', 'C', 'O', '0', '0', '1', '\n'};
+
+bool disk_cache_load(const std::string &dir, const std::string &material, std::vector<char> &code)
+{
+    if (dir.empty()) return false;
+    FILE *f = std::fopen((dir + "/" + disk_cache_name(material)).c_str(), "rb");
+    if (!f) return false;
+    bool ok = false;
+    char magic[8];
+    uint64_t nk = 0, nc = 0;
+    if (std::fread(magic, 1, 8, f) == 8 && std::memcmp(magic, DISK_MAGIC, 8) == 0 && std::fread(&nk, 8, 1, f) == 1 &&
+        nk == material.size()) {
+        std::string have(nk, '\0');
+        if (std::fread(&have[0], 1, nk, f) == nk && have == material && std::fread(&nc, 8, 1, f) == 1 && nc > 0 &&
+            nc < ((uint64_t)1 << 28)) {
+            code.resize(nc);
+            ok = std::fread(code.data(), 1, nc, f) == nc && std::fgetc(f) == EOF;
+        }
+    }
+    std::fclose(f);
+    if (!ok) code.clear();
+    return ok;
+}
+
+void disk_cache_store(const std::string &dir, const std::string &material, const std::vector<char> &code)
+{
+    if (dir.empty() || code.empty()) return;
+    const size_t slash = dir.find_last_of('/');
+    if (slash != std::string::npos && slash > 0) (void)mkdir(dir.substr(0, slash).c_str(), 0700);   // ~/.cache
+    (void)mkdir(dir.c_str(), 0700);
+    const std::string final_name = dir + "/" + disk_cache_name(material);
+    const std::string tmp = final_name + ".tmp" + std::to_string((long)getpid());
+    FILE *f = std::fopen(tmp.c_str(), "wb");
+    if (!f) return;
+    const uint64_t nk = material.size(), nc = code.size();
+    const bool ok = std::fwrite(DISK_MAGIC, 1, 8, f) == 8 && std::fwrite(&nk, 8, 1, f) == 1 &&
+                    std::fwrite(material.data(), 1, nk, f) == nk && std::fwrite(&nc, 8, 1, f) == 1 &&
+                    std::fwrite(code.data(), 1, nc, f) == nc;
+    const bool closed = std::fclose(f) == 0;
+    if (!ok || !closed || std::rename(tmp.c_str(), final_name.c_str()) != 0) (void)std::remove(tmp.c_str());
 }
 
 struct Entry {
@@ -115,8 +195,8 @@ void evict_unused_locked()
 
 hipFunction_t jit_static_kernel(int device, int n_obj, bool spec, const float4 *geom_host, std::string &err)
 {
-    if (n_obj < 0 || n_obj > MAX_STATIC_OBJECTS) { err = "more objects than the by-value kernel takes"; return nullptr; }
-    const int NS = n_obj <= 4 ? 4 : MAX_STATIC_OBJECTS;
+    if (n_obj < 0 || n_obj > MAX_JIT_OBJECTS) { err = "more objects than a scene kernel takes"; return nullptr; }
+    const int NS = n_obj <= 4 ? 4 : n_obj <= MAX_STATIC_OBJECTS ? MAX_STATIC_OBJECTS : MAX_JIT_OBJECTS;
     // the geometry exactly as launch_trace_ns pads it
     std::vector<float> g((size_t)NS * 12, 0.0f);
     for (int k = 0; k < NS; ++k) {
@@ -136,7 +216,10 @@ hipFunction_t jit_static_kernel(int device, int n_obj, bool spec, const float4 *
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) { (void)hipGetLastError(); err = "hipGetDeviceProperties failed"; return nullptr; }
     const std::string arch = std::string("--offload-arch=") + prop.gcnArchName;
     std::vector<char> code;
-    // PT_SCENE_KERNEL_CO: a code object built outside (experiments on the kernel's assembly, tools/rebank.py)
+#ifdef PT_EXPERIMENTS
+    // PT_SCENE_KERNEL_CO: a code object built outside (experiments on the kernel's assembly, tools/rebank.py).  It has
+    // ONE scene baked in and is loaded for whatever scene is asked for, so it exists only in builds made with
+    // `make EXP=-DPT_EXPERIMENTS`; the shipped library never loads code it did not compile from its own source.
     if (const char *co = getenv("PT_SCENE_KERNEL_CO")) {
         if (FILE *f = std::fopen(co, "rb")) {
             char buf[65536];
@@ -146,6 +229,10 @@ hipFunction_t jit_static_kernel(int device, int n_obj, bool spec, const float4 *
         }
         if (code.empty()) { err = std::string("PT_SCENE_KERNEL_CO: cannot read ") + co; return nullptr; }
     }
+#endif
+    bool from_disk = false;
+    std::string material;                                  // everything the code object depends on (disk cache)
+    const std::string cache_dir = disk_cache_dir();
     if (code.empty()) {
     if (!r.ok) { err = "libhiprtc.so not found or incomplete"; return nullptr; }
 
@@ -169,6 +256,10 @@ hipFunction_t jit_static_kernel(int device, int n_obj, bool spec, const float4 *
 
     const char *headers[] = {src_pt_static_kernel_hpp, src_pt_internal_hpp, src_pt_device_hpp};
     const char *names[] = {"pt_static_kernel.hpp", "pt_internal.hpp", "pt_device.hpp"};
+    material = src + "\n//" + arch + "\n//" + r.where + "\n//" + (getenv("PT_JIT_FLAGS") ? getenv("PT_JIT_FLAGS") : "") + "\n" +
+               src_pt_static_kernel_hpp + src_pt_internal_hpp + src_pt_device_hpp;
+    from_disk = disk_cache_load(cache_dir, material, code);
+    if (!from_disk) {
     rtc_program prog = nullptr;
     if (r.create(&prog, src.c_str(), "pt_scene_kernel.hip", 3, headers, names) != 0) { err = "hiprtcCreateProgram failed"; return nullptr; }
     std::vector<const char *> opts = {arch.c_str(), "-O3", "-std=c++17", "-fno-slp-vectorize"};   // the Makefile's code-generation flags
@@ -197,11 +288,18 @@ hipFunction_t jit_static_kernel(int device, int n_obj, bool spec, const float4 *
     code.resize(n);
     r.code(prog, code.data());
     r.destroy(&prog);
+    disk_cache_store(cache_dir, material, code);
+    }
     }
 
     Entry e;
     hipError_t he = hipModuleLoadData(&e.mod, code.data());
-    if (he != hipSuccess) { (void)hipGetLastError(); err = std::string("hipModuleLoadData: ") + hipGetErrorString(he); return nullptr; }
+    if (he != hipSuccess) {
+        (void)hipGetLastError();
+        err = std::string("hipModuleLoadData: ") + hipGetErrorString(he);
+        if (from_disk) (void)std::remove((cache_dir + "/" + disk_cache_name(material)).c_str());   // a file that does not load is not kept
+        return nullptr;
+    }
     const std::string sym = "_ZN2pt19trace_static_kernelILi" + std::to_string(NS) + "ELb" + (spec ? "1" : "0") +
                             "EEEvNS_9TraceArgsENS_10StaticGeomIXT_EEE";
     he = hipModuleGetFunction(&e.fn, e.mod, sym.c_str());
@@ -219,7 +317,8 @@ hipFunction_t jit_static_kernel(int device, int n_obj, bool spec, const float4 *
         (void)hipGetLastError();
     }
     e.info = r.where + ", " + arch + ", __builtin_amdgcn_inverse_ballot_w64 " +
-             (has == 1 ? "available" : has == 0 ? "missing (v_cndmask_b32 form)" : "unknown");
+             (has == 1 ? "available" : has == 0 ? "missing (v_cndmask_b32 form)" : "unknown") +
+             (from_disk ? ", code object from the on-disk cache " + cache_dir : ", compiled in this process");
     e.device = device; e.users = 1; e.stamp = ++g_clock;
     g_cache.emplace(std::move(key), e);
     evict_unused_locked();

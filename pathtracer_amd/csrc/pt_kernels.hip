@@ -1026,9 +1026,13 @@ static hipError_t launch_trace_ns(TraceArgs a, const float4 *geom_host, bool reu
                 void *params[] = {&a, &sg};
                 e = hipModuleLaunchKernel(scene_kernel, sgrid.x, sgrid.y, 1, STATIC_BLOCK, 1, 1, extra_lds, s, params, nullptr);
             } else {
-                if (spec) hipLaunchKernelGGL((trace_static_kernel<NS, true>), sgrid, sblock, extra_lds, s, a, sg);
-                else      hipLaunchKernelGGL((trace_static_kernel<NS, false>), sgrid, sblock, extra_lds, s, a, sg);
-                e = hipGetLastError();
+                if constexpr (NS <= MAX_STATIC_OBJECTS) {
+                    if (spec) hipLaunchKernelGGL((trace_static_kernel<NS, true>), sgrid, sblock, extra_lds, s, a, sg);
+                    else      hipLaunchKernelGGL((trace_static_kernel<NS, false>), sgrid, sblock, extra_lds, s, a, sg);
+                    e = hipGetLastError();
+                } else {
+                    e = hipErrorInvalidValue;                  // 9-16 objects by value: as a scene kernel only
+                }
             }
             if (e == hipSuccess && a.n_slices > 1) {
                 const size_t n4 = (size_t)npix * 3 / 4;
@@ -1087,6 +1091,8 @@ hipError_t launch_trace(const TraceArgs &a, const float4 *geom_host, bool reuse,
     if (a.n_obj <= 4) return launch_trace_ns<4>(a, geom_host, reuse, spec, steal, s, scene_kernel);
     if (a.n_obj <= MAX_STATIC_OBJECTS)
         return launch_trace_ns<MAX_STATIC_OBJECTS>(a, geom_host, reuse, spec, steal, s, scene_kernel);
+    if (scene_kernel && a.n_obj <= MAX_JIT_OBJECTS && reuse && steal && !lds_tiles)
+        return launch_trace_ns<MAX_JIT_OBJECTS>(a, geom_host, reuse, spec, steal, s, scene_kernel);
     if (lds_tiles) return launch_trace_ns<-1>(a, geom_host, reuse, spec, false, s);
     if (a.n_nodes > 0) return launch_trace_ns<-2>(a, geom_host, reuse, spec, steal, s);
     return launch_trace_ns<0>(a, geom_host, reuse, spec, steal, s);

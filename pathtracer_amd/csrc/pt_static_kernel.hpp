@@ -192,8 +192,10 @@ __device__ __forceinline__ void closest_static(const StaticGeom<NS> &sg, const f
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
 #ifdef PT_JIT
-        const float4 g0 = sg.g[k][0];                              // (-n_raw, A) in VGPRs, as in the general kernel
         const float4 c0 = make_float4(JIT_GEOM[k][0], JIT_GEOM[k][1], JIT_GEOM[k][2], JIT_GEOM[k][3]);
+        // (-n_raw, A): in VGPRs, as in the general kernel, for up to 8 objects; beyond that 4 registers per object are
+        // more than the kernel has, and the numbers ride in the instructions as literals (v_fmamk/v_fmaak_f32)
+        const float4 g0 = NS <= 8 ? sg.g[k][0] : make_float4(-c0.x, -c0.y, -c0.z, c0.w);
         const float4 g1 = make_float4(JIT_GEOM[k][4], JIT_GEOM[k][5], JIT_GEOM[k][6], JIT_GEOM[k][7]);
         const float4 g2 = make_float4(JIT_GEOM[k][8], JIT_GEOM[k][9], JIT_GEOM[k][10], JIT_GEOM[k][11]);
 #else
@@ -285,7 +287,9 @@ __global__ __launch_bounds__(STATIC_BLOCK) void trace_static_kernel(TraceArgs a,
     constexpr int R = NS + 1;                       // material records per field: miss + NS objects
     // lane masks of "the primary object is k" and "the last-struck object is k" (closest_static, MASKS)
 #ifdef PT_JIT
-    constexpr bool MASKS = true;      // (8 objects too: their geometry is in the code, not in 64 SGPRs, so the masks fit)
+    // (8 objects too: their geometry is in the code, not in 64 SGPRs, so the masks fit; 16 objects' masks -- three
+    // SGPR pairs each -- do not: the 9-16-object scene kernels keep identity in a VGPR, as the general 8-object one)
+    constexpr bool MASKS = NS <= 8;
 #else
     constexpr bool MASKS = NS <= 4;
 #endif
@@ -299,24 +303,26 @@ __global__ __launch_bounds__(STATIC_BLOCK) void trace_static_kernel(TraceArgs a,
     __shared__ float    s_acc[MASKS ? 1 : BLOCK * 3];   // (!MASKS) per pixel: radiance gathered in phase 2
     const int tid = threadIdx.x;
     signal_gate(a);
-    if (tid < 4 * R) {
-        const int f = tid / R, r = tid - f * R;
+    for (int q = tid; q < 4 * R; q += BLOCK) {
+        const int f = q / R, r = q - f * R;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (r > 0 && r - 1 < a.n_obj) {
             v = a.mat[(r - 1) * 4 + f];
             if (f == 0) v.w = v.w > 0.f ? v.w : (v.w < 0.f ? -2.f : -1.f);   // light e | diffuse -1 | reflective -2
         }
-        s_mat[tid] = v;                             // miss record: colour 0, tag 0
+        s_mat[q] = v;                               // miss record: colour 0, tag 0
     }
     auto matp = [&](int p, int f) -> float4 {       // p = 16*(k+1): byte offset of the record within a field
         return *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s_mat) + p + f * R * 16);
     };
     {   // -n_raw and A to VGPRs (see the header comment; negated so that A - o.n_raw is one fma chain)
         auto fv = [](float &x) { x = __uint_as_float(to_vgpr(__float_as_uint(x))); };
+        if constexpr (NS <= MAX_STATIC_OBJECTS) {
 #pragma unroll
-        for (int k = 0; k < NS; ++k) {
-            sg.g[k][0].x = -sg.g[k][0].x; sg.g[k][0].y = -sg.g[k][0].y; sg.g[k][0].z = -sg.g[k][0].z;
-            fv(sg.g[k][0].x); fv(sg.g[k][0].y); fv(sg.g[k][0].z); fv(sg.g[k][0].w);
+            for (int k = 0; k < NS; ++k) {
+                sg.g[k][0].x = -sg.g[k][0].x; sg.g[k][0].y = -sg.g[k][0].y; sg.g[k][0].z = -sg.g[k][0].z;
+                fv(sg.g[k][0].x); fv(sg.g[k][0].y); fv(sg.g[k][0].z); fv(sg.g[k][0].w);
+            }
         }
     }
 

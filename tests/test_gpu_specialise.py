@@ -34,7 +34,16 @@ def _mixed(pa, n):
          pa.Object((0.3, 0.9, 0.4), 0, False, pa.Sphere((-10.0, -5.0, 60.0), 8.0), "ball"),
          pa.Object((0.9, 0.9, 0.2), 0, False, pa.Rectangle((25, 0, 60), (-1, 0, 0), 60, 40), "card"),
          pa.Object((1, 1, 1), 0, False, pa.InfinitePlane((0, 40, 0), (0, -2, 0)), "wall, normal of length 2"),
-         pa.Object((0.5, 0.5, 0.5), 0, True, pa.InfinitePlane((-30, 0, 0), (1, 0, 0)), "mirror floor")]
+         pa.Object((0.5, 0.5, 0.5), 0, True, pa.InfinitePlane((-30, 0, 0), (1, 0, 0)), "mirror floor"),
+         # 9-16: scene kernels only (the general path for these is the streamed object list)
+         pa.Object((0.7, 0.2, 0.6), 0, False, pa.Disk((-12, 18, 55), (0.1, -0.9, -0.3), 9), "plate"),
+         pa.Object((0.2, 0.6, 0.9), 0, False, pa.Sphere((12.0, -14.0, 45.0), 5.0), "small ball"),
+         pa.Object((0.9, 0.6, 0.2), 0, False, pa.Rectangle((-20, -10, 80), (0.5, 0.2, -1), 30, 20), "tilted card"),
+         pa.Object((1, 1, 1), 1.5, True, pa.Disk((20, 20, 30), (-0.4, -0.4, 0.6), 6), "second lamp"),
+         pa.Object((0.6, 0.9, 0.9), 0, True, pa.Sphere((0.0, 25.0, 65.0), 7.0), "mirror ball"),
+         pa.Object((0.4, 0.4, 0.9), 0, False, pa.Disk((-25, 30, 40), (1, -1, 0), 12), "disk in the corner"),
+         pa.Object((0.9, 0.3, 0.9), 0, False, pa.Rectangle((0, -29, 50), (0, 1, 0), 25, 25), "rug on the tilted wall"),
+         pa.Object((0.3, 0.3, 0.3), 0, False, pa.Disk((10, 0, 99), (0, 0, -1), 15), "picture on the back wall")]
     return o[:n]
 
 
@@ -56,6 +65,33 @@ def test_mixed_scenes_bit_for_bit(pa, n):
     assert sa == sb
     assert np.array_equal(a, b)
     assert a.sum() > 0
+
+
+@pytest.mark.parametrize("n", [9, 12, 16])
+def test_scene_kernels_for_nine_to_sixteen_objects(pa, n):
+    """9-16 objects have no general by-value kernel (their geometry would not fit the scalar registers): the general
+    path streams the object list.  The scene kernel carries the geometry in its code, so the search's arithmetic, the
+    paths and pt_segments are the same; the canvases are compared to fp32 summation order and, when the two kernels
+    happen to add a pixel's samples in the same order, found equal bit for bit."""
+    P = pa.Params(120, 150, 90.0, 1, 6)
+    objs = _mixed(pa, n)
+    a, sa = _render(pa, P, objs, 48, False)
+    b, sb = _render(pa, P, objs, 48, True)
+    assert sa == sb
+    np.testing.assert_allclose(b, a, rtol=4e-6, atol=1e-6)
+    assert a.sum() > 0
+    print(f"{n} objects: scene kernel vs streamed list bit for bit: {np.array_equal(a, b)}")
+    # sliced (>= 512 samples) and repeated launches through the scene kernel
+    with pa.Renderer(P, objs, seed=3) as r:
+        assert r.specialise(), r.last_error()
+        assert "hiprtc" in r.jit_info()
+        r.trace(520); r.trace(8)
+        c, sc = r.read_sum_f32(), r.segments
+    with pa.Renderer(P, objs, seed=3) as r:
+        r.trace(520); r.trace(8)
+        np.testing.assert_allclose(c, r.read_sum_f32(), rtol=4e-6, atol=1e-6)
+        # (the streamed kernel repeats the per-pixel primary search in its second launch; the by-value kernels keep it)
+        assert sc + 120 * 150 == r.segments
 
 
 def test_sliced_and_repeated_launches(pa):
@@ -85,7 +121,7 @@ def test_where_it_does_not_apply(pa):
     P = pa.Params(32, 32, 90.0, 1, 4)
     with pa.Renderer(P, pa.random_disk_scene(40, 1)) as r:      # not a by-value scene
         assert not r.specialise()
-        assert "8 objects" in r.last_error()
+        assert "16 objects" in r.last_error()
         r.trace(4)
     with pa.Renderer(P, pa.objects, flags=pa.PT_FLAG_NO_STEAL) as r:
         assert not r.specialise()
@@ -127,3 +163,48 @@ def test_scene_kernels_are_shared_kept_and_unloaded(pa):
         assert r.specialise() and pa.Renderer.jit_cache_size() == n
         r.trace(2)
         assert r.read_sum_f32().any()
+
+
+def test_scene_kernels_are_kept_on_disk(pa, tmp_path):
+    """The on-disk cache of compiled scene kernels (pt_jit.hip): a second PROCESS with the same scene, library and
+    compiler loads the code object from $PT_KERNEL_CACHE instead of compiling it, and renders the same canvas bit for
+    bit; another scene is another file; PT_KERNEL_CACHE=off keeps the directory untouched; a damaged file is a miss."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prog = ("import sys, json, hashlib; sys.path.insert(0, %r)\n"
+            "import pathtracer_amd as pa\n"
+            "objs = pa.objects if sys.argv[1] == 'default' else pa.objects[:3]\n"
+            "with pa.Renderer(pa.Params(96, 80, 500.0, 1, 6), objs, seed=3) as r:\n"
+            "    assert r.specialise(), r.last_error()\n"
+            "    r.trace(24)\n"
+            "    print(json.dumps({'info': r.jit_info(), 'sha': hashlib.sha256(r.read_sum_f32().tobytes()).hexdigest()}))\n" % root)
+
+    def run(scene, cache):
+        env = dict(os.environ, PT_KERNEL_CACHE=cache)
+        env.pop("PT_SPECIALISE", None)
+        p = subprocess.run([sys.executable, "-c", prog, scene], env=env, capture_output=True, text=True, timeout=120)
+        assert p.returncode == 0, p.stderr[-2000:]
+        return json.loads(p.stdout.strip().splitlines()[-1])
+
+    cache = tmp_path / "kernels"
+    first = run("default", str(cache))
+    assert "compiled in this process" in first["info"]
+    files = sorted(os.listdir(cache))
+    assert len(files) == 1 and files[0].endswith(".co")
+    second = run("default", str(cache))
+    assert "from the on-disk cache" in second["info"] and second["sha"] == first["sha"]
+    assert sorted(os.listdir(cache)) == files
+    other = run("three planes", str(cache))                 # another scene: compiled, a second file
+    assert "compiled in this process" in other["info"] and len(os.listdir(cache)) == 2
+    off = tmp_path / "unused"
+    assert "compiled in this process" in run("default", "off")["info"] and not off.exists()
+    # a truncated file is not trusted: compiled again (and replaced)
+    path = cache / files[0]
+    data = path.read_bytes()
+    path.write_bytes(data[: len(data) // 2])
+    again = run("default", str(cache))
+    assert "compiled in this process" in again["info"] and again["sha"] == first["sha"]
+    assert path.read_bytes() == data or len(path.read_bytes()) == len(data)

@@ -1,4 +1,5 @@
 #!/bin/bash
+# (PT_HIPRTC needs a library built with `make -C pathtracer_amd/csrc EXP=-DPT_EXPERIMENTS`)
 # jit_flags_ab.sh -- the scene kernel of the default scene (PT_SPECIALISE=1) under different compiler options
 # (PT_JIT_FLAGS) and compilers (PT_HIPRTC): per-launch time by HIP events and the canvas checksum, which must not change.
 # usage (GPU box, repo root): tools/jit_flags_ab.sh [spp]
