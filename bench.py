@@ -561,7 +561,9 @@ def main():
             # 513.5 G gathers/s = 8,216 GB/s from an L1-resident table; 267-282 G/s = 4.3-4.5 TB/s once the table
             # only fits L2 -- the kernel's hot top levels sit in between).
             nodes, recs = r.bvh_counters()
-            gathers = (nodes + recs) / max(launches, 1)
+            pad = r.bvh_padding_gathers()               # the empty slot of odd leaves: fetched, not algorithmic
+            fetched = (nodes + recs) / max(launches, 1)
+            gathers = (nodes + recs - pad) / max(launches, 1)
             ach = gathers * 16 / (kern_ms * 1e-3) / 1e9
             out["roofline"] = {"bound": "l1-gather", "achieved": round(ach, 1), "peak": GATHER_PEAK_GBS, "unit": "GB/s",
                                "frac": round(ach / GATHER_PEAK_GBS, 4), "traffic": None,
@@ -569,11 +571,14 @@ def main():
                                "kernel_ms_mode": out["roofline"]["kernel_ms_mode"],
                                "gathers_per_segment": round(gathers / max(segs_launch_rank0, 1), 2),
                                "index_nodes_per_segment": round(nodes / max(launches, 1) / max(segs_launch_rank0, 1), 2),
-                               "object_record_gathers_per_segment": round(recs / max(launches, 1) / max(segs_launch_rank0, 1), 2),
+                               "object_record_gathers_per_segment": round((recs - pad) / max(launches, 1) / max(segs_launch_rank0, 1), 2),
+                               "padding_gathers_per_segment": round(pad / max(launches, 1) / max(segs_launch_rank0, 1), 2),
+                               "fetched_gb_per_s": round(fetched * 16 / (kern_ms * 1e-3) / 1e9, 1),
                                "segments_per_launch": int(segs_launch_rank0),
                                "note": "divergent 16-byte per-lane gathers (index nodes and object records) bound this "
                                        "kernel; algorithmic bytes = 16 B x gathers counted by the kernel "
-                                       "(pt_bvh_counters); peak = measured rate of such gathers from an L1-resident "
+                                       "(pt_bvh_counters) without the empty slot that leaves with an odd number of "
+                                       "objects fetch (pt_bvh_padding_gathers; fetched_gb_per_s includes it); peak = measured rate of such gathers from an L1-resident "
                                        "table (tools/ubench_gather.hip, profiles/r02_bvh_roofline.txt); the linear-scan "
                                        "flop formula of SURVEY 8d does not describe an indexed search"}
         if args.scene != "default":

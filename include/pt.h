@@ -223,6 +223,11 @@ int pt_samples_done(pt_ctx *ctx, int64_t *out);
  * first device.  Any pointer may be NULL.  No counterpart in the reference,
  * whose closestObjectTo is a linear scan (src/Lib.hs:81-98). */
 int pt_bvh_counters(pt_ctx *ctx, uint64_t *node_gathers, uint64_t *record_gathers);
+/* The part of record_gathers that fetched nothing useful: leaves' records are
+ * fetched two slots at a time, and a leaf with an odd number of objects fetches
+ * one empty slot (three gathers).  Algorithmic gathers = node_gathers +
+ * record_gathers - this. */
+int pt_bvh_padding_gathers(pt_ctx *ctx, uint64_t *padding_gathers);
 
 /* Device-side access for hosts that own GPU memory (torch, RCCL): the canvas
  * device pointer (H*W*3 floats) for an all-reduce, the stream the context

@@ -75,6 +75,7 @@ SIGNATURES = {
     "pt_segments": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
     "pt_samples_done": (C.c_int, [_P, C.POINTER(C.c_int64)]),
     "pt_bvh_counters": (C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "pt_bvh_padding_gathers": (C.c_int, [_P, _P]),
     "pt_canvas_device_ptr": (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_size_t)]),
     "pt_set_stream": (C.c_int, [_P, _P]),
     "pt_synchronize": (C.c_int, [_P]),

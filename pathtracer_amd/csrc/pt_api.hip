@@ -687,6 +687,20 @@ int pt_bvh_counters(pt_ctx *c, uint64_t *node_visits, uint64_t *records)
     return PT_OK;
 }
 
+int pt_bvh_padding_gathers(pt_ctx *c, uint64_t *padding)
+{
+    if (int s = check_ctx(c)) return s;
+    if (!padding) return fail(c, PT_ERR_INVALID, "pt_bvh_padding_gathers: null argument");
+    if (c->group) c = group_first(c);
+    unsigned long long lanes[SEG_EPOCH];
+    PT_HIP(c, hipMemcpyAsync(lanes, c->d_segments + (size_t)c->seg_slot * SEG_EPOCH, sizeof lanes, hipMemcpyDeviceToHost, c->stream));
+    PT_HIP(c, hipStreamSynchronize(c->stream));
+    unsigned long long v = 0;
+    for (int l = 0; l < SEG_LANES; ++l) v += lanes[l * SEG_LANE_STRIDE + 3];
+    *padding = (uint64_t)v;
+    return PT_OK;
+}
+
 int pt_samples_done(pt_ctx *c, int64_t *out)
 {
     if (!c || !out) return fail(c, PT_ERR_INVALID, "pt_samples_done: null argument");

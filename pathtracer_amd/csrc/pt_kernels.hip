@@ -701,7 +701,7 @@ __global__ __launch_bounds__(BVH_BLOCK) void trace_bvh_kernel(TraceArgs a)
     uint32_t segs = in_canvas ? 1u : 0u;                   // the fp64 primary search below (a lane runs < 2^32 searches per launch)
     // what bounds this kernel: 16-byte per-lane gathers (one per node visited, three per object record).
     // Counted per lane, summed per wave at the end, next to the segment counter (pt_bvh_counters, include/pt.h).
-    uint32_t n_nodes_visited = 0, n_records = 0;
+    uint32_t n_nodes_visited = 0, n_records = 0, n_padding = 0;   // (n_padding: the part of n_records spent on the empty slot of odd leaves)
     f3 acc = mk3(0.f, 0.f, 0.f);
     if (in_canvas && !a.fresh) acc = mk3(a.canvas[3 * (size_t)pc + 0], a.canvas[3 * (size_t)pc + 1], a.canvas[3 * (size_t)pc + 2]);
 
@@ -756,6 +756,9 @@ __global__ __launch_bounds__(BVH_BLOCK) void trace_bvh_kernel(TraceArgs a)
     const float4 *__restrict__ g = a.bvh_geom;
     const float4 *__restrict__ nodes = a.bvh_nodes;
     int wn = -1, wsp = 0, wbest = -1;
+#ifdef PT_BVH_PAIR
+    int wc = 0;
+#endif
     uint32_t wkey = KEY_LIMIT, neg = 0;
     float wbt = __builtin_inff(), ix = 0.f, iy = 0.f, iz = 0.f;
     auto test = [&](float4 g0, float4 g1, float4 g2, bool on) {
@@ -870,7 +873,72 @@ __global__ __launch_bounds__(BVH_BLOCK) void trace_bvh_kernel(TraceArgs a)
                 }
             }
         } else {
-            // ---- walk: up to PT_BVH_ROUND_VISITS nodes and one leaf per searching lane
+            // ---- walk: up to PT_BVH_ROUND_VISITS steps and one leaf per searching lane
+#ifdef PT_BVH_PAIR
+            // (A/B form, measured 3-5 % slower: profiles/r03_bvh.txt)  A step fetches BOTH children of a node whose box the ray reaches (two independent 16-byte gathers in
+            // flight, one round trip), tests both boxes, goes on with the nearer one that is reached -- its record,
+            // and with it its own children's place, is already there -- and stacks the farther one only if it is
+            // reached too.  Against one node per step: a child the ray misses costs no round trip of its own, and
+            // a descent of d levels takes d round trips instead of d + 1; the gathers are the same in number (a
+            // stacked node is fetched again when it is popped, and tested against the best hit of THAT moment).
+            // State: wn >= 0: a node to fetch and test (the root, a popped node); wn == -2: wc is the code of a
+            // node that was fetched and is reached, to be expanded; wn == -1: the search is over.
+            if (walking) {
+                int code = -1, steps = 0;
+                while (wn != -1 && steps < PT_BVH_ROUND_VISITS) {
+                    int c;
+                    if (wn >= 0) {
+                        const float4 nd = nodes[wn];
+                        n_nodes_visited += 1u;
+                        steps += 1;
+                        if (!slab_hit(nd, o.x, o.y, o.z, ix, iy, iz, wbt)) { wn = pop(); continue; }
+                        c = __float_as_int(nd.w);
+                    } else {
+                        c = wc;
+                    }
+                    if (c >= 0) { code = c; break; }
+                    const int cc = -(c + 1), left = cc >> 2;
+                    const float4 nl = nodes[left], nr = nodes[left + 1];
+                    n_nodes_visited += 2u;
+                    steps += 1;
+                    const bool hl = slab_hit(nl, o.x, o.y, o.z, ix, iy, iz, wbt);
+                    const bool hr = slab_hit(nr, o.x, o.y, o.z, ix, iy, iz, wbt);
+                    const bool right_first = (neg >> (cc & 3)) & 1u;
+                    const bool hn = right_first ? hr : hl, hf = right_first ? hl : hr;
+                    const int cn = __float_as_int(right_first ? nr.w : nl.w), cf = __float_as_int(right_first ? nl.w : nr.w);
+                    if (hn && hf) {
+                        stack[wsp * BLOCK] = (STK)(right_first ? left : left + 1);
+                        wsp += 1;
+                    }
+                    if (hn | hf) { wc = hn ? cn : cf; wn = -2; }
+                    else wn = pop();
+                }
+                if (code >= 0) {
+                    const int first = code >> 3, cnt = (code & 7) + 1;
+                    n_records += 3u * (uint32_t)((cnt + 1) & ~1);     // 16-byte gathers: three per record slot (slots are fetched in pairs)
+                    n_padding += 3u * (uint32_t)(cnt & 1);
+#pragma unroll 1
+                    for (int h = 0; h < BVH_LEAF_SLOTS; h += 2) {
+                        // (fetching a record's third vector only where its plane distance can still win saves 10 % of
+                        // the gathers and costs 4.5 % in time -- a second dependent round trip per pair; measured, dropped.
+                        // Not fetching the pair's second slot when the leaf's count is odd saves 5-9 % of the gathers and
+                        // changes the time by -1...+3 %, as constants under a lane mask (82 VGPRs) or as a single record
+                        // behind the pairs; measured, dropped: profiles/r02_bvh_roofline.txt)
+                        float4 r[2][3];
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            r[q][0] = g[3 * (first + h + q)]; r[q][1] = g[3 * (first + h + q) + 1]; r[q][2] = g[3 * (first + h + q) + 2];
+                        }
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) test(r[q][0], r[q][1], r[q][2], h + q < cnt);
+                        if (h + 2 >= cnt) break;
+                    }
+                    wn = pop();
+                }
+                if (wn == -1) { walking = false; ready = true; }
+            }
+        }
+#else
             if (walking) {
                 int code = -1, steps = 0;
                 while (wn >= 0 && steps < PT_BVH_ROUND_VISITS) {
@@ -890,6 +958,7 @@ __global__ __launch_bounds__(BVH_BLOCK) void trace_bvh_kernel(TraceArgs a)
                 if (code >= 0) {
                     const int first = code >> 3, cnt = (code & 7) + 1;
                     n_records += 3u * (uint32_t)((cnt + 1) & ~1);     // 16-byte gathers: three per record slot (slots are fetched in pairs)
+                    n_padding += 3u * (uint32_t)(cnt & 1);
 #pragma unroll 1
                     for (int h = 0; h < BVH_LEAF_SLOTS; h += 2) {
                         // (fetching a record's third vector only where its plane distance can still win saves 10 % of
@@ -911,6 +980,7 @@ __global__ __launch_bounds__(BVH_BLOCK) void trace_bvh_kernel(TraceArgs a)
                 if (wn < 0) { walking = false; ready = true; }
             }
         }
+#endif
 #ifdef PT_BVH_CLOCKS
         { const long long dc = clock64() - c_in; if (shading) { clk_shade += dc; n_shade += 1; } else { clk_walk += dc; n_walk += 1; } }
 #endif
@@ -924,7 +994,7 @@ __global__ __launch_bounds__(BVH_BLOCK) void trace_bvh_kernel(TraceArgs a)
         a.canvas[3 * (size_t)pc + 1] = s_acc[tid * 3 + 1];
         a.canvas[3 * (size_t)pc + 2] = s_acc[tid * 3 + 2];
     }
-    unsigned long long wsegs = segs, wnodes = n_nodes_visited, wrecs = n_records;
+    unsigned long long wsegs = segs, wnodes = n_nodes_visited, wrecs = n_records, wpad = n_padding;
 #ifdef PT_BVH_CLOCKS
     wnodes = (tid & 63) == 0 ? (unsigned long long)clk_shade : 0ull;      // experiment: clocks in shade / walk steps
     wrecs = (tid & 63) == 0 ? (unsigned long long)clk_walk : 0ull;
@@ -935,12 +1005,14 @@ __global__ __launch_bounds__(BVH_BLOCK) void trace_bvh_kernel(TraceArgs a)
         wsegs += __shfl_down(wsegs, off, 64);
         wnodes += __shfl_down(wnodes, off, 64);
         wrecs += __shfl_down(wrecs, off, 64);
+        wpad += __shfl_down(wpad, off, 64);
     }
     if ((tid & 63) == 0 && wsegs) {
-        unsigned long long *line = seg_lane(a.segments);              // one 128-byte line: [0] segments, [1] nodes, [2] records
+        unsigned long long *line = seg_lane(a.segments);              // one 128-byte line: [0] segments, [1] nodes, [2] records, [3] of which padding
         atomicAdd(line, wsegs);
         atomicAdd(line + 1, wnodes);
         atomicAdd(line + 2, wrecs);
+        atomicAdd(line + 3, wpad);
     }
 }
 
@@ -1059,7 +1131,9 @@ static hipError_t launch_trace_ns(TraceArgs a, const float4 *geom_host, bool reu
                 a.bvh_cache_nodes = cache_env >= 0 ? cache_env : BVH_CACHE_NODES;
                 if (a.bvh_cache_nodes > a.n_nodes) a.bvh_cache_nodes = a.n_nodes;
                 const dim3 bgrid((npix + BVH_BLOCK - 1) / BVH_BLOCK), bblock(BVH_BLOCK);
-                const size_t bsm = (size_t)a.bvh_cache_nodes * sizeof(float4) +
+                // PT_BVH_EXTRA_LDS=<bytes>: unused LDS per workgroup, to lower the waves per CU (occupancy experiment)
+                static const size_t bvh_extra_lds = getenv("PT_BVH_EXTRA_LDS") ? (size_t)atoi(getenv("PT_BVH_EXTRA_LDS")) : 0;
+                const size_t bsm = (size_t)a.bvh_cache_nodes * sizeof(float4) + bvh_extra_lds +
                                    (size_t)(a.bvh_depth + 1) * BVH_BLOCK * (s16 ? sizeof(uint16_t) : sizeof(int));
                 if (s16) {
                     if (spec) hipLaunchKernelGGL((trace_bvh_kernel<true, uint16_t>), bgrid, bblock, bsm, s, a);

@@ -127,6 +127,12 @@ class Renderer:
         check(lib.pt_bvh_counters(self._ctx, C.byref(a), C.byref(b)), self._ctx)
         return a.value, b.value
 
+    def bvh_padding_gathers(self) -> int:
+        """The part of bvh_counters()[1] spent on the empty slot of leaves with an odd number of objects."""
+        a = C.c_uint64()
+        check(lib.pt_bvh_padding_gathers(self._ctx, C.byref(a)), self._ctx)
+        return a.value
+
     @property
     def samples_done(self) -> int:
         v = C.c_int64()
