@@ -248,6 +248,10 @@ void pt_destroy(pt_ctx *c)
     if (c->d_bvh_nodes) (void)hipFree(c->d_bvh_nodes);
     if (c->d_bvh_prims) (void)hipFree(c->d_bvh_prims);
     if (c->d_bvh_geom) (void)hipFree(c->d_bvh_geom);
+    if (c->d_bvh_geom32) (void)hipFree(c->d_bvh_geom32);
+    if (c->d_bvh_mat) (void)hipFree(c->d_bvh_mat);
+    if (c->d_bvh_rect) (void)hipFree(c->d_bvh_rect);
+    if (c->d_bvh_pos) (void)hipFree(c->d_bvh_pos);
     if (c->d_rgb) (void)hipFree(c->d_rgb);
     if (c->d_hits) (void)hipFree(c->d_hits);
     comm_destroy(c);
@@ -300,6 +304,10 @@ int pt_scene_upload(pt_ctx *c, const pt_object *objs, int32_t n)
     if (c->d_bvh_nodes) { (void)hipFree(c->d_bvh_nodes); c->d_bvh_nodes = nullptr; }
     if (c->d_bvh_prims) { (void)hipFree(c->d_bvh_prims); c->d_bvh_prims = nullptr; }
     if (c->d_bvh_geom) { (void)hipFree(c->d_bvh_geom); c->d_bvh_geom = nullptr; }
+    if (c->d_bvh_geom32) { (void)hipFree(c->d_bvh_geom32); c->d_bvh_geom32 = nullptr; }
+    if (c->d_bvh_mat) { (void)hipFree(c->d_bvh_mat); c->d_bvh_mat = nullptr; }
+    if (c->d_bvh_rect) { (void)hipFree(c->d_bvh_rect); c->d_bvh_rect = nullptr; }
+    if (c->d_bvh_pos) { (void)hipFree(c->d_bvh_pos); c->d_bvh_pos = nullptr; }
     c->n_nodes = c->n_unbounded = 0;
     c->n_obj = 0;
     c->have_scene = false;
@@ -366,6 +374,45 @@ int pt_scene_upload(pt_ctx *c, const pt_object *objs, int32_t n)
             PT_HIP(c, hipMemcpy(c->d_bvh_geom, lg.data(), lg.size() * sizeof(float4), hipMemcpyHostToDevice));
             c->n_nodes = (int)bvh.nodes.size();
             c->n_unbounded = bvh.n_unbounded;
+            // The compact form for trace_bvh_kernel (TraceArgs::bvh_geom32): possible when the raw normal of every
+            // finite plane-like form is its unit normal bit for bit in fp32 -- the object test then reads the same
+            // numbers from two vectors that it read from three -- (PT_BVH_REC48 in the environment keeps the
+            // 48-byte records, for A/B).
+            bool compact = !getenv("PT_BVH_REC48");
+            for (size_t sl = (size_t)bvh.n_unbounded; sl < bvh.prims.size() && compact; ++sl) {
+                const int k = bvh.prims[sl];
+                if (objs[k].kind == PT_SPHERE) continue;
+                const float4 g0 = geom[(size_t)k * 3], g1 = geom[(size_t)k * 3 + 1];
+                compact = std::memcmp(&g0.x, &g1.x, 4) == 0 && std::memcmp(&g0.y, &g1.y, 4) == 0 && std::memcmp(&g0.z, &g1.z, 4) == 0;
+            }
+            if (compact) {
+                const size_t nf = bvh.prims.size() - (size_t)bvh.n_unbounded;
+                std::vector<float4> g32((nf + BVH_LEAF_MAX) * 2), pm(bvh.prims.size() * 4), pr2(has_rect ? bvh.prims.size() * 2 : 0);
+                std::vector<int32_t> pos((size_t)n, 0);
+                for (size_t q = 0; q < nf + BVH_LEAF_MAX; ++q) {
+                    const int k = q < nf ? bvh.prims[(size_t)bvh.n_unbounded + q] : n;     // n: a never-hit pad record
+                    const float4 g0 = geom[(size_t)k * 3], g1 = geom[(size_t)k * 3 + 1], g2 = geom[(size_t)k * 3 + 2];
+                    const bool sphere = k < n && objs[k].kind == PT_SPHERE;
+                    g32[q * 2] = sphere ? make_float4(g1.x, g1.y, g1.z, g0.w) : make_float4(g0.x, g0.y, g0.z, g0.w);
+                    g32[q * 2 + 1] = make_float4(g2.x, g2.y, g2.z, g1.w);
+                }
+                for (size_t sl = 0; sl < bvh.prims.size(); ++sl) {
+                    const int k = bvh.prims[sl];
+                    pos[(size_t)k] = (int32_t)sl;
+                    for (int f = 0; f < 4; ++f) pm[sl * 4 + f] = mat[(size_t)k * 4 + f];
+                    if (has_rect) { pr2[sl * 2] = rect[(size_t)k * 2]; pr2[sl * 2 + 1] = rect[(size_t)k * 2 + 1]; }
+                }
+                PT_HIP(c, hipMalloc((void **)&c->d_bvh_geom32, g32.size() * sizeof(float4)));
+                PT_HIP(c, hipMemcpy(c->d_bvh_geom32, g32.data(), g32.size() * sizeof(float4), hipMemcpyHostToDevice));
+                PT_HIP(c, hipMalloc((void **)&c->d_bvh_mat, pm.size() * sizeof(float4)));
+                PT_HIP(c, hipMemcpy(c->d_bvh_mat, pm.data(), pm.size() * sizeof(float4), hipMemcpyHostToDevice));
+                PT_HIP(c, hipMalloc((void **)&c->d_bvh_pos, pos.size() * sizeof(int32_t)));
+                PT_HIP(c, hipMemcpy(c->d_bvh_pos, pos.data(), pos.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+                if (has_rect) {
+                    PT_HIP(c, hipMalloc((void **)&c->d_bvh_rect, pr2.size() * sizeof(float4)));
+                    PT_HIP(c, hipMemcpy(c->d_bvh_rect, pr2.data(), pr2.size() * sizeof(float4), hipMemcpyHostToDevice));
+                }
+            }
         }
     }
     // PT_SPECIALISE=1 in the environment: pt_scene_specialise for every scene it applies to (how the whole GPU
@@ -387,6 +434,7 @@ static void scene_args(const pt_ctx *c, TraceArgs &a)
     a.camera_depth = c->p.camera_depth;
     a.n_obj = c->n_obj; a.height = c->p.height; a.width = c->p.width;
     a.bvh_nodes = c->d_bvh_nodes; a.bvh_prims = c->d_bvh_prims; a.bvh_geom = c->d_bvh_geom;
+    a.bvh_geom32 = c->d_bvh_geom32; a.bvh_mat = c->d_bvh_mat; a.bvh_rect = c->d_bvh_rect; a.bvh_pos = c->d_bvh_pos;
     a.n_nodes = c->n_nodes; a.n_unbounded = c->n_unbounded; a.bvh_depth = c->bvh_depth;
 }
 

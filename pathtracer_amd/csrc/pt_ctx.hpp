@@ -30,6 +30,8 @@ struct pt_ctx {
     float4 *d_bvh_nodes = nullptr;               // spatial index over the finite forms (pt_bvh.hpp), or null
     int32_t *d_bvh_prims = nullptr;
     float4 *d_bvh_geom = nullptr;
+    float4 *d_bvh_geom32 = nullptr, *d_bvh_mat = nullptr, *d_bvh_rect = nullptr;   // the indexed kernel's compact form (TraceArgs::bvh_geom32), or null
+    int32_t *d_bvh_pos = nullptr;
     int n_nodes = 0, n_unbounded = 0, bvh_depth = 0;
     uint8_t *d_rgb = nullptr;
     void *d_hits = nullptr;            // device staging of pt_primary_hits (idx, t, normal: 36 B per pixel), kept between calls

@@ -48,6 +48,15 @@ struct TraceArgs {
     const float4  *bvh_nodes;          // 1 float4 per node: six binary16 box bounds + code (pt_bvh.hpp)
     const int32_t *bvh_prims;          // [unbounded objects..., finite objects in leaf order...]
     const float4  *bvh_geom;           // geometry records in bvh_prims order (3 float4 each, object index in [2].w), padded
+    // trace_bvh_kernel's compact form, present when every finite form's raw normal is already unit (n_raw = n_hat
+    // bit for bit in fp32; spheres have none): TWO float4 per finite object in leaf order -- (n_hat, A) (centre, r^2 |
+    // -r^2 | NaN) -- so that a record costs two 16-byte gathers instead of three.  A record no longer carries its
+    // object's index: inside that kernel an object is named by its POSITION in bvh_prims, and materials, rectangle
+    // sides and the object -> position map are given in that order.
+    const float4  *bvh_geom32;         // (n_prims - n_unbounded + pad) * 2 float4, or null: the 48-byte records
+    const float4  *bvh_mat;            // 4 float4 per position
+    const float4  *bvh_rect;           // 2 float4 per position, or null
+    const int32_t *bvh_pos;            // position of object k
     // Sample slices of one launch (trace_static_kernel): slice y = blockIdx.y traces samples
     // [slice_j0[y], slice_j0[y] + slice_n[y]) of the launch's n_samples; slice 0 continues the canvas, slice
     // y > 0 writes plane y - 1 of `partial`, and slice_sum_kernel adds the planes to the canvas in order.

@@ -673,7 +673,9 @@ constexpr int BVH_BLOCK = 64;
 #endif
 constexpr int BVH_CACHE_NODES = 0;      // see BVH_BLOCK
 
-template <bool SPEC, typename STK>
+// REC32: the compact object records (TraceArgs::bvh_geom32) -- two 16-byte gathers per record instead of three; an
+// object is then named by its position in bvh_prims, and materials / rectangle sides come in that order.
+template <bool SPEC, typename STK, bool REC32>
 __global__ __launch_bounds__(BVH_BLOCK) void trace_bvh_kernel(TraceArgs a)
 {
     constexpr int BLOCK = BVH_BLOCK;
@@ -684,7 +686,9 @@ __global__ __launch_bounds__(BVH_BLOCK) void trace_bvh_kernel(TraceArgs a)
     __shared__ uint32_t s_next[BLOCK];          // per pixel: next sample (launch-local index) not started
     __shared__ float4   s_pix[BLOCK * 3];       // per pixel: P0, d0, colour0, idx0, e0
     __shared__ float    s_acc[BLOCK * 3];       // per pixel: radiance gathered for it by other lanes
-    auto mat = [&](int k, int f) -> float4 { return a.mat[k * 4 + f]; };
+    const float4 *__restrict__ const mats = REC32 ? a.bvh_mat : a.mat;
+    const float4 *__restrict__ const rects = REC32 ? a.bvh_rect : a.rect;
+    auto mat = [&](int k, int f) -> float4 { return mats[k * 4 + f]; };
 
     const int tid = threadIdx.x;
     const int wbase = tid & ~63;                           // this wave's first slot in the per-pixel arrays
@@ -711,6 +715,7 @@ __global__ __launch_bounds__(BVH_BLOCK) void trace_bvh_kernel(TraceArgs a)
     f3 cP0 = mk3((float)(ph.t * ph.dx), (float)(ph.t * ph.dy), (float)(ph.t * ph.dz));
     f3 ccol = mk3(1.f, 1.f, 1.f);
     int cidx = ph.idx; float ce = 0.f;
+    if (REC32 && cidx >= 0) cidx = a.bvh_pos[cidx];        // from here on the object's position in bvh_prims
     bool traced = in_canvas && cidx >= 0 && B >= 2;       // else every sample is black (src/Lib.hs:68,72)
     if (in_canvas && cidx >= 0) {
         const float4 m0 = mat(cidx, 0);
@@ -754,6 +759,7 @@ __global__ __launch_bounds__(BVH_BLOCK) void trace_bvh_kernel(TraceArgs a)
 
     // ---- the resumable closest-hit search (closest<-2>'s arithmetic) ----------
     const float4 *__restrict__ g = a.bvh_geom;
+    const float4 *__restrict__ g32 = a.bvh_geom32;
     const float4 *__restrict__ nodes = a.bvh_nodes;
     int wn = -1, wsp = 0, wbest = -1;
 #ifdef PT_BVH_PAIR
@@ -761,15 +767,14 @@ __global__ __launch_bounds__(BVH_BLOCK) void trace_bvh_kernel(TraceArgs a)
 #endif
     uint32_t wkey = KEY_LIMIT, neg = 0;
     float wbt = __builtin_inff(), ix = 0.f, iy = 0.f, iz = 0.f;
-    auto test = [&](float4 g0, float4 g1, float4 g2, bool on) {
-        const int k = __float_as_int(g2.w);
+    auto test = [&](float4 g0, float4 g1, float4 g2, int k, bool on) {
         const float num = fmaf(-o.z, g0.z, fmaf(-o.y, g0.y, fmaf(-o.x, g0.x, g0.w)));
         const float den = fmaf(d.z, g1.z, fmaf(d.y, g1.y, d.x * g1.x));
         float t = num * __builtin_amdgcn_rcpf(den);
         const float dx = fmaf(t, d.x, o.x) - g2.x;             // Disk (src/Object.hs:165-171); a plane has r2 = +Inf
         const float dy = fmaf(t, d.y, o.y) - g2.y;
         const float dz = fmaf(t, d.z, o.z) - g2.z;
-        bool inside = inside_form<SPEC>(a.rect, k, g1.w, dx, dy, dz) || (g1.w == __builtin_inff());
+        bool inside = inside_form<SPEC>(rects, k, g1.w, dx, dy, dz) || (g1.w == __builtin_inff());
         if constexpr (SPEC) {
             const float ts = sphere_t(mk3(g2.x, g2.y, g2.z), -g1.w, o, d);
             t = (g1.w < 0.0f) ? ts : t;
@@ -777,14 +782,17 @@ __global__ __launch_bounds__(BVH_BLOCK) void trace_bvh_kernel(TraceArgs a)
         }
         uint32_t key = __float_as_uint(t) - 1u;
         key = (k == last || !on || !inside) ? KEY_INVALID : key;     // _lastStruck (src/Lib.hs:86-90)
-        const bool better = (key < wkey) | ((key == wkey) & (key < KEY_LIMIT) & (k < wbest));
+        bool better = key < wkey;
+        const bool tie = (key == wkey) & (key < KEY_LIMIT);          // an equal t keeps the lower OBJECT index (minimumBy)
+        if constexpr (REC32) { if (tie) better = a.bvh_prims[k] < a.bvh_prims[wbest]; }
+        else better = better | (tie & (k < wbest));
         wbest = better ? k : wbest;
         wkey = better ? key : wkey;
         wbt = better ? t : wbt;
     };
     auto begin_search = [&]() {
         wbest = -1; wkey = KEY_LIMIT; wbt = __builtin_inff();
-        for (int u = 0; u < a.n_unbounded; ++u) test(g[3 * u], g[3 * u + 1], g[3 * u + 2], true);
+        for (int u = 0; u < a.n_unbounded; ++u) test(g[3 * u], g[3 * u + 1], g[3 * u + 2], REC32 ? u : __float_as_int(g[3 * u + 2].w), true);
         ix = __builtin_amdgcn_rcpf(d.x); iy = __builtin_amdgcn_rcpf(d.y); iz = __builtin_amdgcn_rcpf(d.z);
         neg = (d.x < 0.f ? 1u : 0u) | (d.y < 0.f ? 2u : 0u) | (d.z < 0.f ? 4u : 0u);
         wn = 0; wsp = 0;
@@ -915,8 +923,8 @@ __global__ __launch_bounds__(BVH_BLOCK) void trace_bvh_kernel(TraceArgs a)
                 }
                 if (code >= 0) {
                     const int first = code >> 3, cnt = (code & 7) + 1;
-                    n_records += 3u * (uint32_t)((cnt + 1) & ~1);     // 16-byte gathers: three per record slot (slots are fetched in pairs)
-                    n_padding += 3u * (uint32_t)(cnt & 1);
+                    n_records += (REC32 ? 2u : 3u) * (uint32_t)((cnt + 1) & ~1);     // 16-byte gathers: three (two) per record slot (slots are fetched in pairs)
+                    n_padding += (REC32 ? 2u : 3u) * (uint32_t)(cnt & 1);
 #pragma unroll 1
                     for (int h = 0; h < BVH_LEAF_SLOTS; h += 2) {
                         // (fetching a record's third vector only where its plane distance can still win saves 10 % of
@@ -924,13 +932,24 @@ __global__ __launch_bounds__(BVH_BLOCK) void trace_bvh_kernel(TraceArgs a)
                         // Not fetching the pair's second slot when the leaf's count is odd saves 5-9 % of the gathers and
                         // changes the time by -1...+3 %, as constants under a lane mask (82 VGPRs) or as a single record
                         // behind the pairs; measured, dropped: profiles/r02_bvh_roofline.txt)
-                        float4 r[2][3];
+                        if constexpr (REC32) {
+                            float4 r[2][2];
 #pragma unroll
-                        for (int q = 0; q < 2; ++q) {
-                            r[q][0] = g[3 * (first + h + q)]; r[q][1] = g[3 * (first + h + q) + 1]; r[q][2] = g[3 * (first + h + q) + 2];
+                            for (int q = 0; q < 2; ++q) {
+                                r[q][0] = g32[2 * (first - a.n_unbounded + h + q)]; r[q][1] = g32[2 * (first - a.n_unbounded + h + q) + 1];
+                            }
+#pragma unroll
+                            for (int q = 0; q < 2; ++q)      // (n_hat, A) (centre, r^2): n_raw = n_hat in this form
+                                test(r[q][0], make_float4(r[q][0].x, r[q][0].y, r[q][0].z, r[q][1].w), r[q][1], first + h + q, h + q < cnt);
+                        } else {
+                            float4 r[2][3];
+#pragma unroll
+                            for (int q = 0; q < 2; ++q) {
+                                r[q][0] = g[3 * (first + h + q)]; r[q][1] = g[3 * (first + h + q) + 1]; r[q][2] = g[3 * (first + h + q) + 2];
+                            }
+#pragma unroll
+                            for (int q = 0; q < 2; ++q) test(r[q][0], r[q][1], r[q][2], __float_as_int(r[q][2].w), h + q < cnt);
                         }
-#pragma unroll
-                        for (int q = 0; q < 2; ++q) test(r[q][0], r[q][1], r[q][2], h + q < cnt);
                         if (h + 2 >= cnt) break;
                     }
                     wn = pop();
@@ -957,8 +976,8 @@ __global__ __launch_bounds__(BVH_BLOCK) void trace_bvh_kernel(TraceArgs a)
                 }
                 if (code >= 0) {
                     const int first = code >> 3, cnt = (code & 7) + 1;
-                    n_records += 3u * (uint32_t)((cnt + 1) & ~1);     // 16-byte gathers: three per record slot (slots are fetched in pairs)
-                    n_padding += 3u * (uint32_t)(cnt & 1);
+                    n_records += (REC32 ? 2u : 3u) * (uint32_t)((cnt + 1) & ~1);     // 16-byte gathers: three (two) per record slot (slots are fetched in pairs)
+                    n_padding += (REC32 ? 2u : 3u) * (uint32_t)(cnt & 1);
 #pragma unroll 1
                     for (int h = 0; h < BVH_LEAF_SLOTS; h += 2) {
                         // (fetching a record's third vector only where its plane distance can still win saves 10 % of
@@ -966,13 +985,24 @@ __global__ __launch_bounds__(BVH_BLOCK) void trace_bvh_kernel(TraceArgs a)
                         // Not fetching the pair's second slot when the leaf's count is odd saves 5-9 % of the gathers and
                         // changes the time by -1...+3 %, as constants under a lane mask (82 VGPRs) or as a single record
                         // behind the pairs; measured, dropped: profiles/r02_bvh_roofline.txt)
-                        float4 r[2][3];
+                        if constexpr (REC32) {
+                            float4 r[2][2];
 #pragma unroll
-                        for (int q = 0; q < 2; ++q) {
-                            r[q][0] = g[3 * (first + h + q)]; r[q][1] = g[3 * (first + h + q) + 1]; r[q][2] = g[3 * (first + h + q) + 2];
+                            for (int q = 0; q < 2; ++q) {
+                                r[q][0] = g32[2 * (first - a.n_unbounded + h + q)]; r[q][1] = g32[2 * (first - a.n_unbounded + h + q) + 1];
+                            }
+#pragma unroll
+                            for (int q = 0; q < 2; ++q)      // (n_hat, A) (centre, r^2): n_raw = n_hat in this form
+                                test(r[q][0], make_float4(r[q][0].x, r[q][0].y, r[q][0].z, r[q][1].w), r[q][1], first + h + q, h + q < cnt);
+                        } else {
+                            float4 r[2][3];
+#pragma unroll
+                            for (int q = 0; q < 2; ++q) {
+                                r[q][0] = g[3 * (first + h + q)]; r[q][1] = g[3 * (first + h + q) + 1]; r[q][2] = g[3 * (first + h + q) + 2];
+                            }
+#pragma unroll
+                            for (int q = 0; q < 2; ++q) test(r[q][0], r[q][1], r[q][2], __float_as_int(r[q][2].w), h + q < cnt);
                         }
-#pragma unroll
-                        for (int q = 0; q < 2; ++q) test(r[q][0], r[q][1], r[q][2], h + q < cnt);
                         if (h + 2 >= cnt) break;
                     }
                     wn = pop();
@@ -1135,13 +1165,12 @@ static hipError_t launch_trace_ns(TraceArgs a, const float4 *geom_host, bool reu
                 static const size_t bvh_extra_lds = getenv("PT_BVH_EXTRA_LDS") ? (size_t)atoi(getenv("PT_BVH_EXTRA_LDS")) : 0;
                 const size_t bsm = (size_t)a.bvh_cache_nodes * sizeof(float4) + bvh_extra_lds +
                                    (size_t)(a.bvh_depth + 1) * BVH_BLOCK * (s16 ? sizeof(uint16_t) : sizeof(int));
-                if (s16) {
-                    if (spec) hipLaunchKernelGGL((trace_bvh_kernel<true, uint16_t>), bgrid, bblock, bsm, s, a);
-                    else      hipLaunchKernelGGL((trace_bvh_kernel<false, uint16_t>), bgrid, bblock, bsm, s, a);
-                } else {
-                    if (spec) hipLaunchKernelGGL((trace_bvh_kernel<true, int>), bgrid, bblock, bsm, s, a);
-                    else      hipLaunchKernelGGL((trace_bvh_kernel<false, int>), bgrid, bblock, bsm, s, a);
-                }
+                const bool r32 = a.bvh_geom32 != nullptr;          // the compact records (pt_scene_upload decides)
+#define PT_BVH_LAUNCH(SP, ST) do { if (r32) hipLaunchKernelGGL((trace_bvh_kernel<SP, ST, true>), bgrid, bblock, bsm, s, a); \
+                                   else     hipLaunchKernelGGL((trace_bvh_kernel<SP, ST, false>), bgrid, bblock, bsm, s, a); } while (0)
+                if (s16) { if (spec) PT_BVH_LAUNCH(true, uint16_t); else PT_BVH_LAUNCH(false, uint16_t); }
+                else     { if (spec) PT_BVH_LAUNCH(true, int);      else PT_BVH_LAUNCH(false, int); }
+#undef PT_BVH_LAUNCH
                 return hipGetLastError();
             }
             if (spec) hipLaunchKernelGGL((trace_steal_kernel<NS, true>), tgrid, tblock, ssm, s, a, sg, a.geom);
