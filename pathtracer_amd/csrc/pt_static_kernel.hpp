@@ -293,14 +293,18 @@ __global__ __launch_bounds__(STATIC_BLOCK) void trace_static_kernel(TraceArgs a,
 #else
     constexpr bool MASKS = NS <= 4;
 #endif
-    // Per pixel of the wave, one record: (P0, record offset), (colour0, e0), (d0, -) and, MASKS, the sharing phase's
-    // state in the same record -- the next global sample index not started in [2].w, the radiance handed over by
-    // helpers in [3].xyz -- so that ONE per-lane LDS address (raddr) names everything of the pixel a lane works on.
-    constexpr int RV = MASKS ? 4 : 3;
+    // Per pixel of the wave, one record of three vectors: (P0, record offset), (colour0, e0), (d0, next) -- next, MASKS:
+    // the sharing phase's counter of the pixel, the next global sample index not started -- and, MASKS, the radiance
+    // handed over by helpers in s_hand at a quarter of the record's offset, so that ONE per-lane LDS address (raddr)
+    // names everything of the pixel a lane works on.  48-byte records: the 16 lanes a ds_read_b128 serves per pass
+    // start at 12 banks' distance, all different bank quads; with the sums inside a 64-byte record they started 16
+    // banks apart, four lanes per quad -- SQ_LDS_BANK_CONFLICT was 30 % of SQ_LDS_IDX_ACTIVE, 1.3 % before and after.
+    constexpr int RV = 3;
     __shared__ float4   s_mat[4 * R];               // field f of object k at [f*R + k + 1]; [f*R] = miss
     __shared__ uint32_t s_next[MASKS ? 1 : BLOCK];  // (!MASKS) per pixel: next global sample index not started
     __shared__ float4   s_pix[BLOCK * RV];
     __shared__ float    s_acc[MASKS ? 1 : BLOCK * 3];   // (!MASKS) per pixel: radiance gathered in phase 2
+    __shared__ float    s_hand[MASKS ? BLOCK * 3 : 1];  // (MASKS) the same, addressed as (raddr - rbase) / 4
     const int tid = threadIdx.x;
     signal_gate(a);
     for (int q = tid; q < 4 * R; q += BLOCK) {
@@ -353,11 +357,17 @@ __global__ __launch_bounds__(STATIC_BLOCK) void trace_static_kernel(TraceArgs a,
     // The primary segment (src/Lib.hs:41-51, :81-98) has no jitter and uses no randomness: it is the same for every
     // sample and every launch of this camera and scene.  primary_fill_kernel (pt_kernels.hip) computes it once per
     // scene in fp64, in the reference's operation order, and leaves point, direction and record offset in a.pix.
-    f3 cd0, cP0;
+    f3 cd0 = mk3(0.f, 0.f, 0.f), cP0;
     int cidxp;
     {
-        const float4 q0 = a.pix[2 * (size_t)pc], q1 = a.pix[2 * (size_t)pc + 1];
-        cP0 = mk3(q0.x, q0.y, q0.z); cd0 = mk3(q0.w, q1.x, q1.y); cidxp = __float_as_int(q1.z);
+        // (P0, record offset) (d0, -): a diffuse scene's kernel never reads the primary direction -- its bounces do not
+        // depend on the incoming ray (src/Lib.hs:129-132) -- and fetches the first 16 bytes only
+        const float4 q0 = a.pix[2 * (size_t)pc];
+        cP0 = mk3(q0.x, q0.y, q0.z); cidxp = __float_as_int(q0.w);
+        if constexpr (SPEC) {
+            const float4 q1 = a.pix[2 * (size_t)pc + 1];
+            cd0 = mk3(q1.x, q1.y, q1.z);
+        }
     }
     f3 ccol = mk3(1.f, 1.f, 1.f);
     float ce = 0.f;
@@ -554,7 +564,9 @@ __global__ __launch_bounds__(STATIC_BLOCK) void trace_static_kernel(TraceArgs a,
         //             and the primary-object masks of the movers are wave-uniform values (one pixel), set from SGPRs.
         const uint32_t own = rbase + (uint32_t)tid * (RV * 16);
         lds_write_u32(own + 44, alive ? (ctr >> 6) + stride : gs_end);
-        s_pix[tid * RV + 3] = make_float4(0.f, 0.f, 0.f, 0.f);
+        s_hand[tid * 3 + 0] = 0.f; s_hand[tid * 3 + 1] = 0.f; s_hand[tid * 3 + 2] = 0.f;
+        const uint32_t hbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)&s_hand[0];
+        auto hand_addr = [&](uint32_t rec) { return hbase + ((rec - rbase) >> 2); };    // 48-byte records, 12-byte sums
         unsigned long long alive_m = __builtin_amdgcn_ballot_w64(alive);
         thr = mk3(alive ? thr.x : 0.f, alive ? thr.y : 0.f, alive ? thr.z : 0.f);
         const uint32_t stride_v = to_vgpr(stride);
@@ -591,10 +603,11 @@ __global__ __launch_bounds__(STATIC_BLOCK) void trace_static_kernel(TraceArgs a,
                         const uint64_t pre = (uint64_t)0xD256D193u * (uint64_t)(uint32_t)(pixel0 + (int)v);
                         const uint32_t phi = (uint32_t)(pre >> 32), plo = (uint32_t)pre;
                         unsigned long long saved;
+                        const uint32_t ha = hand_addr(raddr);
                         asm volatile("s_and_saveexec_b64 %[sv], %[m]\n\t"
-                                     "ds_add_f32 %[ra], %[ax] offset:48\n\t"
-                                     "ds_add_f32 %[ra], %[ay] offset:52\n\t"
-                                     "ds_add_f32 %[ra], %[az] offset:56\n\t"
+                                     "ds_add_f32 %[ha], %[ax]\n\t"
+                                     "ds_add_f32 %[ha], %[ay] offset:4\n\t"
+                                     "ds_add_f32 %[ha], %[az] offset:8\n\t"
                                      "v_mov_b32 %[ra], %[rv]\n\t"
                                      "v_mov_b32 %[ph], %[sph]\n\t"
                                      "v_mov_b32 %[pl], %[spl]\n\t"
@@ -605,7 +618,7 @@ __global__ __launch_bounds__(STATIC_BLOCK) void trace_static_kernel(TraceArgs a,
                                      "s_mov_b64 exec, %[sv]"
                                      : [ax] "+v"(acc.x), [ay] "+v"(acc.y), [az] "+v"(acc.z), [ra] "+v"(raddr),
                                        [ph] "+v"(pre_hi), [pl] "+v"(pre_lo), [sv] "=&s"(saved)
-                                     : [m] "s"(mv), [rv] "s"(rv), [sph] "s"(phi), [spl] "s"(plo) : "memory");
+                                     : [m] "s"(mv), [rv] "s"(rv), [sph] "s"(phi), [spl] "s"(plo), [ha] "v"(ha) : "memory");
                         const int idx_v = __builtin_amdgcn_readfirstlane((int)lds_read_u32(rv + 12));
 #pragma unroll
                         for (int k = 0; k < NS; ++k)
@@ -627,11 +640,11 @@ __global__ __launch_bounds__(STATIC_BLOCK) void trace_static_kernel(TraceArgs a,
             }
         } while (alive_m != 0ull);
         {   // what the lane still holds goes to the record of the pixel it worked on last
-            asm volatile("ds_add_f32 %[ra], %[ax] offset:48\n\t"
-                         "ds_add_f32 %[ra], %[ay] offset:52\n\t"
-                         "ds_add_f32 %[ra], %[az] offset:56\n\t"
+            asm volatile("ds_add_f32 %[ha], %[ax]\n\t"
+                         "ds_add_f32 %[ha], %[ay] offset:4\n\t"
+                         "ds_add_f32 %[ha], %[az] offset:8\n\t"
                          "s_waitcnt lgkmcnt(0)"
-                         : : [ra] "v"(raddr), [ax] "v"(acc.x), [ay] "v"(acc.y), [az] "v"(acc.z) : "memory");
+                         : : [ha] "v"(hand_addr(raddr)), [ax] "v"(acc.x), [ay] "v"(acc.y), [az] "v"(acc.z) : "memory");
         }
     } else {
         s_next[tid] = alive ? (ctr >> 6) + stride : gs_end;
@@ -693,10 +706,9 @@ __global__ __launch_bounds__(STATIC_BLOCK) void trace_static_kernel(TraceArgs a,
     __syncthreads();
     if (in_canvas) {
         if constexpr (MASKS) {
-            const float4 q = s_pix[tid * RV + 3];
-            canvas[3 * (size_t)pc + 0] = q.x;
-            canvas[3 * (size_t)pc + 1] = q.y;
-            canvas[3 * (size_t)pc + 2] = q.z;
+            canvas[3 * (size_t)pc + 0] = s_hand[tid * 3 + 0];
+            canvas[3 * (size_t)pc + 1] = s_hand[tid * 3 + 1];
+            canvas[3 * (size_t)pc + 2] = s_hand[tid * 3 + 2];
         } else {
             canvas[3 * (size_t)pc + 0] = s_acc[tid * 3 + 0];
             canvas[3 * (size_t)pc + 1] = s_acc[tid * 3 + 1];
