@@ -61,7 +61,7 @@ struct TraceArgs {
     // [slice_j0[y], slice_j0[y] + slice_n[y]) of the launch's n_samples; slice 0 continues the canvas, slice
     // y > 0 writes plane y - 1 of `partial`, and slice_sum_kernel adds the planes to the canvas in order.
     // The primary hits (fp64 pass, per pixel: point, direction, record offset) of this camera and scene, kept
-    // from the first launch for all later ones (trace_static_kernel): 2 float4 per pixel, or null
+    // from the first launch for all later ones (trace_static_kernel): two planes of one float4 per pixel
     float4  *pix;
     int      pix_valid;                // 1: read them, 0: compute (and store if pix != null)
     float   *partial;                  // (MAX_SLICES - 1) * H*W*3 floats, or null: no slicing

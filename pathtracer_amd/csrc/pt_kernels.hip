@@ -1049,7 +1049,7 @@ __global__ __launch_bounds__(BVH_BLOCK) void trace_bvh_kernel(TraceArgs a)
 
 // The primary segment of every pixel for trace_static_kernel: fp64, the reference's operation order (primary_hit_f64,
 // the function the parity hook pt_primary_hits runs), once per camera and scene -- the first launch after
-// pt_scene_upload -- kept in a.pix as (P0, record offset 16*(idx+1)) (d0, -).  The searches are counted.
+// pt_scene_upload -- kept in a.pix as two planes of one float4 per pixel: (P0, record offset 16*(idx+1)), then (d0, -).  The searches are counted.
 __global__ __launch_bounds__(256) void primary_fill_kernel(TraceArgs a)
 {
     const int npix = a.height * a.width;
@@ -1057,9 +1057,9 @@ __global__ __launch_bounds__(256) void primary_fill_kernel(TraceArgs a)
     if (pc < npix) {
         const int pi = pc / a.width, pj = pc - pi * a.width;
         const PrimaryHit ph = primary_hit(a, pi, pj);
-        a.pix[2 * (size_t)pc] = make_float4((float)(ph.t * ph.dx), (float)(ph.t * ph.dy), (float)(ph.t * ph.dz),
+        a.pix[(size_t)pc] = make_float4((float)(ph.t * ph.dx), (float)(ph.t * ph.dy), (float)(ph.t * ph.dz),
                                             __int_as_float(16 * (ph.idx + 1)));
-        a.pix[2 * (size_t)pc + 1] = make_float4((float)ph.dx, (float)ph.dy, (float)ph.dz, 0.f);
+        a.pix[(size_t)npix + (size_t)pc] = make_float4((float)ph.dx, (float)ph.dy, (float)ph.dz, 0.f);
     }
     const unsigned long long n = __builtin_popcountll(__ballot(pc < npix));
     if ((threadIdx.x & 63) == 0 && n) atomicAdd(seg_lane(a.segments), n);

@@ -362,10 +362,10 @@ __global__ __launch_bounds__(STATIC_BLOCK) void trace_static_kernel(TraceArgs a,
     {
         // (P0, record offset) (d0, -): a diffuse scene's kernel never reads the primary direction -- its bounces do not
         // depend on the incoming ray (src/Lib.hs:129-132) -- and fetches the first 16 bytes only
-        const float4 q0 = a.pix[2 * (size_t)pc];
+        const float4 q0 = a.pix[(size_t)pc];                   // two planes of 16 bytes per pixel: whole lines of the first only
         cP0 = mk3(q0.x, q0.y, q0.z); cidxp = __float_as_int(q0.w);
         if constexpr (SPEC) {
-            const float4 q1 = a.pix[2 * (size_t)pc + 1];
+            const float4 q1 = a.pix[(size_t)npix + (size_t)pc];
             cd0 = mk3(q1.x, q1.y, q1.z);
         }
     }
