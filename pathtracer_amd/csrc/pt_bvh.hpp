@@ -11,10 +11,11 @@
 // Layout: binary BVH in BREADTH-first order, one 16-byte node per box, the two
 // children of a node next to each other.  A lane walks it near child first (by
 // the sign of the ray direction along the node's split axis) with a short
-// per-lane stack of far children in LDS; every node is one 16-byte gather.  In
-// level order the first K nodes are the top of the tree -- the nodes every walk
-// visits -- which trace_bvh_kernel keeps in LDS.  Depth is bounded
-// (BVH_MAX_DEPTH) so the stack cannot overflow whatever the scene.
+// per-lane stack of far children in LDS; every node is one 16-byte gather.
+// Node 0 is not a box: index 0 is the walk's "search over" mark (the bottom entry
+// of every lane's stack), the root is node 1 and the pairs of children follow
+// from node 2 on, so a left child's index is even and its sibling is index ^ 1.
+// Depth is bounded (BVH_MAX_DEPTH) so the stack cannot overflow whatever the scene.
 #pragma once
 
 #include <algorithm>
@@ -26,12 +27,15 @@
 
 namespace pt {
 
-// 16 bytes per node = ONE 16-byte gather per step of the walk (the walk is bound
-// by the CU's divergent-gather rate): the box as six binary16
-// values rounded OUTWARD, plus one code word.
-//   h[0..2] = lo.xyz, h[3..5] = hi.xyz   (a coordinate beyond binary16's range becomes +-Inf: still conservative)
-//   code >= 0: leaf, first_prim << 3 | (count - 1)
-//   code <  0: inner node, -(c + 1) with c = left_child << 2 | split_axis; right child = left child + 1
+// 16 bytes per node = ONE 16-byte gather per step of the walk: the box as centre and half-extent, six binary16
+// values, plus one code word.  The device tests it with nine v_fma_mix_f32 (binary16 sources converted inside the
+// fp32 FMA: t = (c -+ e - o) / d as fma(-+e, |1/d|, fma(c, 1/d, -o/d))) instead of six conversions, six subtractions,
+// six multiplications and six min/max (round 3, profiles/r03_bvh_walk.txt).
+//   h[0..2] = centre.xyz rounded to nearest, h[3..5] = half-extent.xyz rounded UP so that [c - e, c + e] evaluated
+//   in fp32 contains the padded box (a coordinate beyond binary16's range gives e = +Inf: still conservative)
+//   code >= 0: inner node, left_child << 5 | split_axis (left_child even; right child = left child + 1)
+//   code <  0: leaf, ~code = first_prim << 3 | (count - 1)
+constexpr int32_t BVH_ROOT = 1;
 struct BvhNode {
     uint16_t h[6];
     int32_t code;
@@ -68,9 +72,18 @@ inline float half_bits_to_float(uint16_t h)
     return (h & 0x8000) ? -v : v;
 }
 
-constexpr int BVH_LEAF_MAX = 6;          // (8 was best while the walk waited on latency; bound by gathered bytes, 6 is: -4 %)
-constexpr int BVH_SAH_DEPTH = 14;       // surface-area splits down to here, balanced median splits below:
-constexpr int BVH_MAX_DEPTH = 30;       //   14 + ceil(log2(65536 / 4)) = 28 levels at most
+#ifndef PT_BVH_LEAF_MAX
+#define PT_BVH_LEAF_MAX 2                // (pt_device.hpp has the same default)
+#endif
+// Objects per leaf: 8 was best while the walk waited on latency (round 1), 6 once it was bound by gathered bytes
+// (round 2); with round 3's walk step (a node visit costs the wave ~24 VALU instructions, a pair of object tests 82)
+// 2 is: 1,000 disks 23.5 -> 19.4 ms, 10,000 disks 85.3 -> 74.5 (profiles/r03_bvh_walk.txt).
+constexpr int BVH_LEAF_MAX = PT_BVH_LEAF_MAX;
+#ifndef PT_BVH_SAH_DEPTH
+#define PT_BVH_SAH_DEPTH 14
+#endif
+constexpr int BVH_SAH_DEPTH = PT_BVH_SAH_DEPTH;       // surface-area splits down to here, balanced median splits below:
+constexpr int BVH_MAX_DEPTH = 30;       //   14 + ceil(log2(65536 / 2)) = 29 levels at most
 constexpr int BVH_STACK = 32;           // per-lane stack entries on the device (> BVH_MAX_DEPTH)
 constexpr int BVH_MIN_FINITE = 16;      // below this the linear scan is used
 
@@ -106,8 +119,9 @@ public:
         // level order: a queue of (range of order_, depth, node index); children are allocated in pairs
         struct Item { int b, e, depth, me; };
         std::vector<Item> queue;
-        out.nodes.push_back(BvhNode{});
-        queue.push_back(Item{0, (int)order_.size(), 0, 0});
+        out.nodes.push_back(BvhNode{});                  // node 0: the "search over" mark, never fetched
+        out.nodes.push_back(BvhNode{});                  // node BVH_ROOT
+        queue.push_back(Item{0, (int)order_.size(), 0, BVH_ROOT});
         for (size_t head = 0; head < queue.size(); ++head) {
             const Item it = queue[head];
             int mid = 0, axis = 0;
@@ -115,7 +129,7 @@ public:
             const int32_t first = (int32_t)out.nodes.size();
             out.nodes.push_back(BvhNode{});
             out.nodes.push_back(BvhNode{});
-            out.nodes[it.me].code = -(((first << 2) | axis) + 1);
+            out.nodes[it.me].code = (first << 5) | axis;        // first is even: pairs start at node 2
             queue.push_back(Item{it.b, mid, it.depth + 1, first});               // the low side of `axis` first
             queue.push_back(Item{mid, it.e, it.depth + 1, first + 1});
             if (it.depth + 1 > max_depth) max_depth = it.depth + 1;
@@ -155,22 +169,32 @@ private:
         const BvhBox bb = bounds(b, e);
         BvhNode n;
         for (int a = 0; a < 3; ++a) {
-            // pad, then round outward to binary16: the device's slab test is plain fp32 on these values
-            n.h[a]     = half_round_dir((float)(bb.lo[a] - pad_) - std::fabs((float)(bb.lo[a] - pad_)) * 1e-7f, false);
-            n.h[3 + a] = half_round_dir((float)(bb.hi[a] + pad_) + std::fabs((float)(bb.hi[a] + pad_)) * 1e-7f, true);
+            // pad, widen by fp32 rounding, then centre to nearest binary16 and the half-extent rounded up to cover
+            // both sides from that centre: the device's test is plain fp32 on these values
+            const float lo = (float)(bb.lo[a] - pad_) - std::fabs((float)(bb.lo[a] - pad_)) * 1e-7f;
+            const float hi = (float)(bb.hi[a] + pad_) + std::fabs((float)(bb.hi[a] + pad_)) * 1e-7f;
+            uint16_t ch = half_round_dir(0.5f * lo + 0.5f * hi, false);
+            if ((ch & 0x7fffu) >= 0x7c00u) ch = (uint16_t)((ch & 0x8000u) | 0x7bffu);     // keep the centre finite
+            const double c = (double)half_bits_to_float(ch);
+            const double ext = std::max((double)hi - c, c - (double)lo);
+            n.h[a]     = ch;
+            n.h[3 + a] = half_round_dir((float)(ext * (1.0 + 2e-7)) + 1e-30f, true);
         }
         const int cnt = e - b;
         if (cnt <= BVH_LEAF_MAX) {
-            n.code = ((prim_base_ + b) << 3) | (cnt - 1);
+            n.code = ~(((prim_base_ + b) << 3) | (cnt - 1));
             out_->nodes[me] = n;
             return false;
         }
-        n.code = -1;
+        n.code = 0;
         out_->nodes[me] = n;
         // binned SAH over the centroids of the widest axes; median split as the fallback
         int best_axis = -1, best_split = -1;
         double best_cost = std::numeric_limits<double>::infinity();
-        constexpr int BINS = 16;
+#ifndef PT_BVH_BINS
+#define PT_BVH_BINS 16
+#endif
+        constexpr int BINS = PT_BVH_BINS;
         for (int a = 0; a < 3 && depth < BVH_SAH_DEPTH; ++a) {
             double cmin = std::numeric_limits<double>::infinity(), cmax = -cmin;
             for (int i = b; i < e; ++i) { cmin = std::min(cmin, centroid(i, a)); cmax = std::max(cmax, centroid(i, a)); }

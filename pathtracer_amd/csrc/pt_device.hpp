@@ -395,22 +395,47 @@ __device__ inline PrimaryHit primary_hit_f64(const double *__restrict__ prim, in
 // runs the arithmetic of the linear scan, and an equal t keeps the lower object
 // index, so the result is the scan's.  The slab test is fp32 on boxes the host
 // rounded outward and padded.
-// node = (lo.xy | lo.z hi.x | hi.yz as binary16 pairs, code): pt_bvh.hpp
-__device__ __forceinline__ bool slab_hit(float4 nd, float ox, float oy, float oz,
-                                         float ix, float iy, float iz, float t_best)
+// node = (c.xy | c.z e.x | e.yz as binary16 pairs, code): centre and half-extent, pt_bvh.hpp
+// The ray's side of the test, computed once per search: 1/d, clamped to +-2^100 so that a direction component of
+// exactly 0 gives finite products (the slab is then open or shut by the sign of (c - o) -+ e alone).
+struct SlabRay { float ix, iy, iz; };
+__device__ __forceinline__ SlabRay slab_ray(float dx, float dy, float dz)
+{
+    SlabRay r;
+    r.ix = __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(dx), -0x1p100f, 0x1p100f);
+    r.iy = __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(dy), -0x1p100f, 0x1p100f);
+    r.iz = __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(dz), -0x1p100f, 0x1p100f);
+    return r;
+}
+// t at the slab's two faces = ((c -+ e) - o) / d = fma(-+e, |1/d|, (c - o) * (1/d)): the near face is the one with -e
+// whatever the sign of d, so no min/max per axis.  Per axis: c - o as one v_fma_mix_f32 (the binary16 source converted
+// inside the fp32 FMA), a multiplication, two more v_fma_mix_f32; then max3 + max, min3 + min, one compare: 17
+// instructions where the lo / hi form took 30 (six conversions, six subtractions, six multiplications, six min/max).
+// (fma(c, 1/d, -o/d) would save the three multiplications and cost three more registers per lane for o/d: the kernel
+// is bound by its gathers and by registers, not by the VALU -- profiles/r03_bvh_walk.txt.)
+// Rounding: three fp32 roundings per face, relative to |c - o| and |t|: in box space < 2e-7 x (|c - o| + e), which the
+// host's padding (2e-5 of the scene's extent) covers while the ray's origin is within ~50 extents of the boxes.
+__device__ __forceinline__ bool slab_hit(float4 nd, float ox, float oy, float oz, const SlabRay &r, float t_best)
 {
     typedef _Float16 h2 __attribute__((ext_vector_type(2)));
     const h2 a = __builtin_bit_cast(h2, nd.x), b = __builtin_bit_cast(h2, nd.y), c = __builtin_bit_cast(h2, nd.z);
-    const float lox = (float)a.x, loy = (float)a.y, loz = (float)b.x, hix = (float)b.y, hiy = (float)c.x, hiz = (float)c.y;
-    const float ax = (lox - ox) * ix, bx = (hix - ox) * ix;
-    const float ay = (loy - oy) * iy, by = (hiy - oy) * iy;
-    const float az = (loz - oz) * iz, bz = (hiz - oz) * iz;
-    const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
-    const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), t_best));
+    const float mx = __builtin_fmaf((float)a.x, 1.0f, -ox) * r.ix;
+    const float my = __builtin_fmaf((float)a.y, 1.0f, -oy) * r.iy;
+    const float mz = __builtin_fmaf((float)b.x, 1.0f, -oz) * r.iz;
+    const float ax = __builtin_fabsf(r.ix), ay = __builtin_fabsf(r.iy), az = __builtin_fabsf(r.iz);
+    const float nx = __builtin_fmaf(-(float)b.y, ax, mx), fx = __builtin_fmaf((float)b.y, ax, mx);
+    const float ny = __builtin_fmaf(-(float)c.x, ay, my), fy = __builtin_fmaf((float)c.x, ay, my);
+    const float nz = __builtin_fmaf(-(float)c.y, az, mz), fz = __builtin_fmaf((float)c.y, az, mz);
+    const float tn = fmaxf(fmaxf(fmaxf(nx, ny), 0.0f), nz);
+    const float tf = fminf(fminf(fminf(fx, fy), t_best), fz);
     return tn <= tf;
 }
 
-constexpr int BVH_LEAF_SLOTS = 8;         // >= BVH_LEAF_MAX of pt_bvh.hpp (a leaf's count has 3 bits)
+#ifndef PT_BVH_LEAF_MAX
+#define PT_BVH_LEAF_MAX 2                 // objects per leaf at most (pt_bvh.hpp builds to it; a leaf's count has 3 bits: <= 8)
+#endif
+constexpr int BVH_LEAF_SLOTS = (PT_BVH_LEAF_MAX + 1) & ~1;     // a leaf's records are fetched two slots at a time
+constexpr int BVH_ROOT_NODE = 1;          // = BVH_ROOT of pt_bvh.hpp: node 0 is the "search over" mark
 
 // Near-child-first walk.  `stack` is this lane's column of an LDS array laid out
 // [entry][lane] (stride = lanes per workgroup): conflict-free, no scratch memory.
@@ -422,30 +447,29 @@ __device__ __forceinline__ void bvh_walk(const float4 *__restrict__ nodes,
                                          float ox, float oy, float oz, float dx, float dy, float dz,
                                          STK *stack, int stride, LeafFn &&leaf, BestFn &&t_best)
 {
-    const float ix = __builtin_amdgcn_rcpf(dx), iy = __builtin_amdgcn_rcpf(dy), iz = __builtin_amdgcn_rcpf(dz);
+    const SlabRay sr = slab_ray(dx, dy, dz);
     const uint32_t neg = (dx < 0.f ? 1u : 0u) | (dy < 0.f ? 2u : 0u) | (dz < 0.f ? 4u : 0u);
     // "while-while" (Aila & Laine, HPG'09): every lane first walks inner nodes until
     // it holds a leaf or runs out of nodes; only then do the lanes test their
     // leaves together.  A wave pays for the (long) leaf block once per round
     // instead of on every step in which any one of its 64 lanes is at a leaf.
-    int sp = 0, n = 0;
+    int sp = 0, n = BVH_ROOT_NODE;
     auto pop = [&]() -> int {
-        if (sp == 0) return -1;
+        if (sp == 0) return 0;
         sp -= 1;
         return (int)stack[sp * stride];
     };
     for (;;) {
         int code = -1;
-        while (n >= 0) {
+        while (n != 0) {
             const float4 nd = nodes[n];
-            if (!slab_hit(nd, ox, oy, oz, ix, iy, iz, t_best())) { n = pop(); continue; }
+            if (!slab_hit(nd, ox, oy, oz, sr, t_best())) { n = pop(); continue; }
             const int c = __float_as_int(nd.w);
-            if (c >= 0) { code = c; break; }
-            const int cc = -(c + 1), left = cc >> 2, right = left + 1;    // siblings are neighbours (pt_bvh.hpp)
-            const bool right_first = (neg >> (cc & 3)) & 1u;
-            stack[sp * stride] = (STK)(right_first ? left : right);
+            if (c < 0) { code = ~c; break; }
+            const int near = (c >> 5) + (int)((neg >> (c & 31)) & 1u);    // siblings are neighbours, the left one even (pt_bvh.hpp)
+            stack[sp * stride] = (STK)(near ^ 1);
             sp += 1;
-            n = right_first ? right : left;
+            n = near;
         }
         if (code < 0) break;
         leaf(code >> 3, (code & 7) + 1);                      // first slot, count (<= 4)

@@ -45,7 +45,7 @@ struct TraceArgs {
     int      fresh;                    // 1: the canvas is logically zero, start the sums at 0 without reading it
     int      tile_objs;                // objects per LDS tile (tiled kernel; set by the launcher)
     // spatial index over the finite forms (pt_bvh.hpp); n_nodes == 0: none, linear scan
-    const float4  *bvh_nodes;          // 1 float4 per node: six binary16 box bounds + code (pt_bvh.hpp)
+    const float4  *bvh_nodes;          // 1 float4 per node: centre and half-extent as six binary16 + code (pt_bvh.hpp); node 0 unused, root = node 1
     const int32_t *bvh_prims;          // [unbounded objects..., finite objects in leaf order...]
     const float4  *bvh_geom;           // geometry records in bvh_prims order (3 float4 each, object index in [2].w), padded
     // trace_bvh_kernel's compact form, present when every finite form's raw normal is already unit (n_raw = n_hat
@@ -73,7 +73,6 @@ struct TraceArgs {
     unsigned long long *gate;
     unsigned long long gate_value;
     int      n_nodes;
-    int      bvh_cache_nodes;          // trace_bvh_kernel: the first this many nodes (level order: the top of the tree) live in LDS
     int      bvh_depth;                // deepest leaf: the walk's stack holds at most this many far children
     int      n_unbounded;
 };

@@ -657,13 +657,13 @@ __global__ __launch_bounds__(NS == -2 ? 64 : TRACE_BLOCK) void trace_steal_kerne
 // paths, the hits and pt_segments are the same; only WHEN a lane does what
 // changes (and with it the fp32 summation order of a pixel's samples).
 // ---------------------------------------------------------------------------
-// One wave per workgroup.  The kernel can keep the top of the tree (the first bvh_cache_nodes nodes in level order,
-// where every walk starts) in LDS, shared by the waves of a workgroup of any size: pools, stacks and sums are per
-// wave, and only the staging of that copy needs a barrier.  MEASURED (profiles/r02_bvh_roofline.txt), it does not
-// pay: four-wave workgroups with 448-960 cached nodes remove every node gather of the 1,000-object scenes and a
-// third of the 10,000-object scene's, and run 12-50 % SLOWER than one-wave workgroups without a cache (fewer
-// waves per CU, one more LDS round trip per step); 64-128 nodes in a one-wave workgroup: +-3 %.  So the default
-// is no cache, and what this round keeps is the 16-bit stack (2-5 % from the occupancy it frees).
+// One wave per workgroup.  (Round 2 could keep the top of the tree in LDS, shared by the waves of a larger workgroup:
+// measured 12-50 % slower with 448-960 nodes, +-3 % with 64-128, profiles/r02_bvh_roofline.txt; removed in round 3 --
+// the choice between an LDS and a global address made every node fetch a flat load.)
+// Round 3 rewrote the walk step around its VALU issue cost (the kernel issues 0.27 wave-instructions per cycle per
+// SIMD against the default scene's 0.34: the VALU, not the gathers, is what its waves queue for): the box test as
+// nine v_fma_mix_f32 on centre / half-extent nodes, one 16-byte global load per node through a scalar base and a
+// 32-bit offset, a stack pointer instead of a depth, index 0 as the "search over" mark at the bottom of the stack.
 constexpr int BVH_BLOCK = 64;
 #ifndef PT_BVH_ROUND_VISITS
 #define PT_BVH_ROUND_VISITS 8
@@ -671,7 +671,6 @@ constexpr int BVH_BLOCK = 64;
 #ifndef PT_BVH_SHADE_LANES
 #define PT_BVH_SHADE_LANES 12
 #endif
-constexpr int BVH_CACHE_NODES = 0;      // see BVH_BLOCK
 
 // REC32: the compact object records (TraceArgs::bvh_geom32) -- two 16-byte gathers per record instead of three; an
 // object is then named by its position in bvh_prims, and materials / rectangle sides come in that order.
@@ -679,10 +678,10 @@ template <bool SPEC, typename STK, bool REC32>
 __global__ __launch_bounds__(BVH_BLOCK) void trace_bvh_kernel(TraceArgs a)
 {
     constexpr int BLOCK = BVH_BLOCK;
-    // dynamic LDS: [top of the tree: bvh_cache_nodes x 16 B][stacks: (bvh_depth + 1) entries x BLOCK lanes x STK]
+    // dynamic LDS: the stacks, (bvh_depth + 2) entries x BLOCK lanes x STK, laid out [entry][lane]; entry 0 holds
+    // node index 0, the "search over" mark, for good
     // (STK = 16 bits while the tree has fewer than 65,536 nodes: the stacks are what limits the waves per CU)
-    const float4 *const s_nodes = s_tile;
-    STK *const stack = reinterpret_cast<STK *>(s_tile + a.bvh_cache_nodes) + threadIdx.x;   // [entry][lane]
+    STK *const stack = reinterpret_cast<STK *>(s_tile) + threadIdx.x;
     __shared__ uint32_t s_next[BLOCK];          // per pixel: next sample (launch-local index) not started
     __shared__ float4   s_pix[BLOCK * 3];       // per pixel: P0, d0, colour0, idx0, e0
     __shared__ float    s_acc[BLOCK * 3];       // per pixel: radiance gathered for it by other lanes
@@ -700,12 +699,17 @@ __global__ __launch_bounds__(BVH_BLOCK) void trace_bvh_kernel(TraceArgs a)
     const int pi = pc / a.width, pj = pc - pi * a.width;
     const uint32_t n = (uint32_t)a.n_samples;
     const int B = a.max_bounces;
-    for (int q = tid; q < a.bvh_cache_nodes; q += BLOCK) s_tile[q] = a.bvh_nodes[q];
 
     uint32_t segs = in_canvas ? 1u : 0u;                   // the fp64 primary search below (a lane runs < 2^32 searches per launch)
     // what bounds this kernel: 16-byte per-lane gathers (one per node visited, three per object record).
     // Counted per lane, summed per wave at the end, next to the segment counter (pt_bvh_counters, include/pt.h).
-    uint32_t n_nodes_visited = 0, n_records = 0, n_padding = 0;   // (n_padding: the part of n_records spent on the empty slot of odd leaves)
+    uint32_t n_nodes_visited = 0, n_records = 0, n_padding = 0;
+#ifdef PT_BVH_STATS
+    uint32_t st_iv = 0, st_il = 0, st_r = 0, st_s = 0;   // wave-iterations (x 4096) of the visit loop, the leaf loop, walk steps, shade steps
+#define PT_STAT(x) x += 4096u / (uint32_t)__popcll(__ballot(true))
+#else
+#define PT_STAT(x) (void)0
+#endif   // (n_padding: the part of n_records spent on the empty slot of odd leaves)
     f3 acc = mk3(0.f, 0.f, 0.f);
     if (in_canvas && !a.fresh) acc = mk3(a.canvas[3 * (size_t)pc + 0], a.canvas[3 * (size_t)pc + 1], a.canvas[3 * (size_t)pc + 2]);
 
@@ -761,20 +765,19 @@ __global__ __launch_bounds__(BVH_BLOCK) void trace_bvh_kernel(TraceArgs a)
     const float4 *__restrict__ g = a.bvh_geom;
     const float4 *__restrict__ g32 = a.bvh_geom32;
     const float4 *__restrict__ nodes = a.bvh_nodes;
-    int wn = -1, wsp = 0, wbest = -1;
-#ifdef PT_BVH_PAIR
-    int wc = 0;
-#endif
+    int wn = 0, wbest = -1;                                // wn: the node to visit next, 0 = the search is over
+    STK *wsp = stack;                                      // this lane's top stack entry
     uint32_t wkey = KEY_LIMIT, neg = 0;
-    float wbt = __builtin_inff(), ix = 0.f, iy = 0.f, iz = 0.f;
-    auto test = [&](float4 g0, float4 g1, float4 g2, int k, bool on) {
+    float wbt = __builtin_inff();
+    SlabRay sr = {0.f, 0.f, 0.f};
+    auto test = [&](float4 g0, float4 g1, float4 g2, int k, bool on, bool finite = true) {    // finite: a leaf's record (no plane)
         const float num = fmaf(-o.z, g0.z, fmaf(-o.y, g0.y, fmaf(-o.x, g0.x, g0.w)));
         const float den = fmaf(d.z, g1.z, fmaf(d.y, g1.y, d.x * g1.x));
         float t = num * __builtin_amdgcn_rcpf(den);
         const float dx = fmaf(t, d.x, o.x) - g2.x;             // Disk (src/Object.hs:165-171); a plane has r2 = +Inf
         const float dy = fmaf(t, d.y, o.y) - g2.y;
         const float dz = fmaf(t, d.z, o.z) - g2.z;
-        bool inside = inside_form<SPEC>(rects, k, g1.w, dx, dy, dz) || (g1.w == __builtin_inff());
+        bool inside = inside_form<SPEC>(rects, k, g1.w, dx, dy, dz) || (!finite && g1.w == __builtin_inff());
         if constexpr (SPEC) {
             const float ts = sphere_t(mk3(g2.x, g2.y, g2.z), -g1.w, o, d);
             t = (g1.w < 0.0f) ? ts : t;
@@ -792,16 +795,19 @@ __global__ __launch_bounds__(BVH_BLOCK) void trace_bvh_kernel(TraceArgs a)
     };
     auto begin_search = [&]() {
         wbest = -1; wkey = KEY_LIMIT; wbt = __builtin_inff();
-        for (int u = 0; u < a.n_unbounded; ++u) test(g[3 * u], g[3 * u + 1], g[3 * u + 2], REC32 ? u : __float_as_int(g[3 * u + 2].w), true);
-        ix = __builtin_amdgcn_rcpf(d.x); iy = __builtin_amdgcn_rcpf(d.y); iz = __builtin_amdgcn_rcpf(d.z);
+        for (int u = 0; u < a.n_unbounded; ++u) test(g[3 * u], g[3 * u + 1], g[3 * u + 2], REC32 ? u : __float_as_int(g[3 * u + 2].w), true, false);
+        sr = slab_ray(d.x, d.y, d.z);
         neg = (d.x < 0.f ? 1u : 0u) | (d.y < 0.f ? 2u : 0u) | (d.z < 0.f ? 4u : 0u);
-        wn = 0; wsp = 0;
+        // (starting below the root -- its code word as a kernel argument, one gather less per search -- was measured:
+        // rays that leave the scene are then turned away by two boxes instead of one, 7.0 instead of 6.4 node visits
+        // per segment on the 1,000-disk scene, 31.6 instead of 32.1 on the 10,000-disk scene, times equal)
+        wn = BVH_ROOT_NODE; wsp = stack;
     };
-    auto pop = [&]() -> int {
-        if (wsp == 0) return -1;
-        wsp -= 1;
-        return (int)stack[wsp * BLOCK];
+    auto pop = [&]() {                                     // (the bottom entry is node 0: popping it ends the search)
+        wn = (int)*wsp;
+        wsp -= BLOCK;
     };
+    stack[0] = (STK)0;                                     // (after primary_hit, which walks with the same stack)
 
     bool live = traced && n > 0;                           // has a path in flight
     bool walking = false, ready = !live;                   // pathless lanes ask the pool for work at the first shade step
@@ -823,6 +829,7 @@ __global__ __launch_bounds__(BVH_BLOCK) void trace_bvh_kernel(TraceArgs a)
             int k = -1; float t = 0.f;
             float4 m0 = make_float4(0.f, 0.f, 0.f, 0.f);
             bool terminal = false;
+            if (ready) { PT_STAT(st_s); }
             if (ready && live) {
                 k = wbest;
                 key_result(k, wkey, t);
@@ -882,97 +889,37 @@ __global__ __launch_bounds__(BVH_BLOCK) void trace_bvh_kernel(TraceArgs a)
             }
         } else {
             // ---- walk: up to PT_BVH_ROUND_VISITS steps and one leaf per searching lane
-#ifdef PT_BVH_PAIR
-            // (A/B form, measured 3-5 % slower: profiles/r03_bvh.txt)  A step fetches BOTH children of a node whose box the ray reaches (two independent 16-byte gathers in
-            // flight, one round trip), tests both boxes, goes on with the nearer one that is reached -- its record,
-            // and with it its own children's place, is already there -- and stacks the farther one only if it is
-            // reached too.  Against one node per step: a child the ray misses costs no round trip of its own, and
-            // a descent of d levels takes d round trips instead of d + 1; the gathers are the same in number (a
-            // stacked node is fetched again when it is popped, and tested against the best hit of THAT moment).
-            // State: wn >= 0: a node to fetch and test (the root, a popped node); wn == -2: wc is the code of a
-            // node that was fetched and is reached, to be expanded; wn == -1: the search is over.
             if (walking) {
                 int code = -1, steps = 0;
-                while (wn != -1 && steps < PT_BVH_ROUND_VISITS) {
-                    int c;
-                    if (wn >= 0) {
-                        const float4 nd = nodes[wn];
-                        n_nodes_visited += 1u;
-                        steps += 1;
-                        if (!slab_hit(nd, o.x, o.y, o.z, ix, iy, iz, wbt)) { wn = pop(); continue; }
-                        c = __float_as_int(nd.w);
-                    } else {
-                        c = wc;
-                    }
-                    if (c >= 0) { code = c; break; }
-                    const int cc = -(c + 1), left = cc >> 2;
-                    const float4 nl = nodes[left], nr = nodes[left + 1];
-                    n_nodes_visited += 2u;
+                PT_STAT(st_r);
+                while (wn != 0 && steps < PT_BVH_ROUND_VISITS) {
+                    PT_STAT(st_iv);
+                    // one 16-byte gather: scalar base + 32-bit byte offset (fewer than 2^26 nodes)
+                    const float4 nd = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(nodes) + ((uint32_t)wn << 4));
+                    int c = __float_as_int(nd.w);
+                    // (the code word is pinned here so that it arrives with the box, in one dwordx4: left alone, the
+                    // compiler fetches it in the hit branch -- a second dependent round trip per node; and the counter
+                    // is an opaque add so that it does not become "base + steps", two copies per step)
+                    asm volatile("v_add_u32 %0, 1, %0" : "+v"(n_nodes_visited), "+v"(c));
                     steps += 1;
-                    const bool hl = slab_hit(nl, o.x, o.y, o.z, ix, iy, iz, wbt);
-                    const bool hr = slab_hit(nr, o.x, o.y, o.z, ix, iy, iz, wbt);
-                    const bool right_first = (neg >> (cc & 3)) & 1u;
-                    const bool hn = right_first ? hr : hl, hf = right_first ? hl : hr;
-                    const int cn = __float_as_int(right_first ? nr.w : nl.w), cf = __float_as_int(right_first ? nl.w : nr.w);
-                    if (hn && hf) {
-                        stack[wsp * BLOCK] = (STK)(right_first ? left : left + 1);
-                        wsp += 1;
+                    if (!slab_hit(nd, o.x, o.y, o.z, sr, wbt)) { pop(); continue; }
+#ifndef PT_BVH_NO_POSTPONE
+                    // a lane that reaches a leaf keeps it for the end of the step and walks on (its best hit is then
+                    // one leaf out of date for the rest of the step); a second leaf ends its step, and is visited
+                    // again by the next one
+                    if (c < 0) {
+                        if (code >= 0) break;
+                        code = ~c; pop(); continue;
                     }
-                    if (hn | hf) { wc = hn ? cn : cf; wn = -2; }
-                    else wn = pop();
-                }
-                if (code >= 0) {
-                    const int first = code >> 3, cnt = (code & 7) + 1;
-                    n_records += (REC32 ? 2u : 3u) * (uint32_t)((cnt + 1) & ~1);     // 16-byte gathers: three (two) per record slot (slots are fetched in pairs)
-                    n_padding += (REC32 ? 2u : 3u) * (uint32_t)(cnt & 1);
-#pragma unroll 1
-                    for (int h = 0; h < BVH_LEAF_SLOTS; h += 2) {
-                        // (fetching a record's third vector only where its plane distance can still win saves 10 % of
-                        // the gathers and costs 4.5 % in time -- a second dependent round trip per pair; measured, dropped.
-                        // Not fetching the pair's second slot when the leaf's count is odd saves 5-9 % of the gathers and
-                        // changes the time by -1...+3 %, as constants under a lane mask (82 VGPRs) or as a single record
-                        // behind the pairs; measured, dropped: profiles/r02_bvh_roofline.txt)
-                        if constexpr (REC32) {
-                            float4 r[2][2];
-#pragma unroll
-                            for (int q = 0; q < 2; ++q) {
-                                r[q][0] = g32[2 * (first - a.n_unbounded + h + q)]; r[q][1] = g32[2 * (first - a.n_unbounded + h + q) + 1];
-                            }
-#pragma unroll
-                            for (int q = 0; q < 2; ++q)      // (n_hat, A) (centre, r^2): n_raw = n_hat in this form
-                                test(r[q][0], make_float4(r[q][0].x, r[q][0].y, r[q][0].z, r[q][1].w), r[q][1], first + h + q, h + q < cnt);
-                        } else {
-                            float4 r[2][3];
-#pragma unroll
-                            for (int q = 0; q < 2; ++q) {
-                                r[q][0] = g[3 * (first + h + q)]; r[q][1] = g[3 * (first + h + q) + 1]; r[q][2] = g[3 * (first + h + q) + 2];
-                            }
-#pragma unroll
-                            for (int q = 0; q < 2; ++q) test(r[q][0], r[q][1], r[q][2], __float_as_int(r[q][2].w), h + q < cnt);
-                        }
-                        if (h + 2 >= cnt) break;
-                    }
-                    wn = pop();
-                }
-                if (wn == -1) { walking = false; ready = true; }
-            }
-        }
 #else
-            if (walking) {
-                int code = -1, steps = 0;
-                while (wn >= 0 && steps < PT_BVH_ROUND_VISITS) {
-                    float4 nd;
-                    if (wn < a.bvh_cache_nodes) nd = s_nodes[wn];      // the top of the tree: LDS
-                    else { nd = nodes[wn]; n_nodes_visited += 1u; }    // below it: a gather
-                    steps += 1;
-                    if (!slab_hit(nd, o.x, o.y, o.z, ix, iy, iz, wbt)) { wn = pop(); continue; }
-                    const int c = __float_as_int(nd.w);
-                    if (c >= 0) { code = c; break; }
-                    const int cc = -(c + 1), left = cc >> 2, right = left + 1;
-                    const bool right_first = (neg >> (cc & 3)) & 1u;
-                    stack[wsp * BLOCK] = (STK)(right_first ? left : right);
-                    wsp += 1;
-                    wn = right_first ? right : left;
+                    if (c < 0) { code = ~c; break; }
+#endif
+                    // inner node: c = left child << 5 | split axis (v_bfe_u32 reads the low five bits of its offset),
+                    // the left child even, its sibling index ^ 1
+                    const int near = (c >> 5) + (int)__builtin_amdgcn_ubfe(neg, (uint32_t)c, 1u);
+                    wsp += BLOCK;
+                    *wsp = (STK)(near ^ 1);
+                    wn = near;
                 }
                 if (code >= 0) {
                     const int first = code >> 3, cnt = (code & 7) + 1;
@@ -980,11 +927,13 @@ __global__ __launch_bounds__(BVH_BLOCK) void trace_bvh_kernel(TraceArgs a)
                     n_padding += (REC32 ? 2u : 3u) * (uint32_t)(cnt & 1);
 #pragma unroll 1
                     for (int h = 0; h < BVH_LEAF_SLOTS; h += 2) {
+                        PT_STAT(st_il);
                         // (fetching a record's third vector only where its plane distance can still win saves 10 % of
                         // the gathers and costs 4.5 % in time -- a second dependent round trip per pair; measured, dropped.
                         // Not fetching the pair's second slot when the leaf's count is odd saves 5-9 % of the gathers and
                         // changes the time by -1...+3 %, as constants under a lane mask (82 VGPRs) or as a single record
-                        // behind the pairs; measured, dropped: profiles/r02_bvh_roofline.txt)
+                        // behind the pairs; measured, dropped: profiles/r02_bvh_roofline.txt; again in round 3 with
+                        // leaves of two, under the lanes' mask: +-0.5 %)
                         if constexpr (REC32) {
                             float4 r[2][2];
 #pragma unroll
@@ -1005,12 +954,13 @@ __global__ __launch_bounds__(BVH_BLOCK) void trace_bvh_kernel(TraceArgs a)
                         }
                         if (h + 2 >= cnt) break;
                     }
-                    wn = pop();
+#ifdef PT_BVH_NO_POSTPONE
+                    pop();
+#endif
                 }
-                if (wn < 0) { walking = false; ready = true; }
+                if (wn == 0) { walking = false; ready = true; }
             }
         }
-#endif
 #ifdef PT_BVH_CLOCKS
         { const long long dc = clock64() - c_in; if (shading) { clk_shade += dc; n_shade += 1; } else { clk_walk += dc; n_walk += 1; } }
 #endif
@@ -1025,6 +975,9 @@ __global__ __launch_bounds__(BVH_BLOCK) void trace_bvh_kernel(TraceArgs a)
         a.canvas[3 * (size_t)pc + 2] = s_acc[tid * 3 + 2];
     }
     unsigned long long wsegs = segs, wnodes = n_nodes_visited, wrecs = n_records, wpad = n_padding;
+#ifdef PT_BVH_STATS
+    wnodes = st_iv; wrecs = st_il; wpad = PT_BVH_STATS == 1 ? st_r : st_s;
+#endif
 #ifdef PT_BVH_CLOCKS
     wnodes = (tid & 63) == 0 ? (unsigned long long)clk_shade : 0ull;      // experiment: clocks in shade / walk steps
     wrecs = (tid & 63) == 0 ? (unsigned long long)clk_walk : 0ull;
@@ -1155,17 +1108,12 @@ static hipError_t launch_trace_ns(TraceArgs a, const float4 *geom_host, bool reu
             if (NS == -2 && !getenv("PT_BVH_LOCKSTEP")) {      // (PT_BVH_LOCKSTEP: the one-search-per-trip loop, for A/B)
                 // LDS per one-wave workgroup: 4 KB of per-pixel pools (static) + the stacks (2.2 KB at depth 16 with
                 // 16-bit entries; 32-bit entries held the kernel to 19 waves per CU, now its 78 VGPRs do: 24) + the
-                // top of the tree, if any (PT_BVH_CACHE_NODES in the environment, read at every launch, for A/B).
-                const char *ce = getenv("PT_BVH_CACHE_NODES");
-                const int cache_env = ce ? atoi(ce) : -1;
+                // "search over" entry at the bottom.
                 const bool s16 = a.n_nodes < 65536 && !getenv("PT_BVH_STACK32");   // (PT_BVH_STACK32: the 32-bit form for any tree, A/B and tests)
-                a.bvh_cache_nodes = cache_env >= 0 ? cache_env : BVH_CACHE_NODES;
-                if (a.bvh_cache_nodes > a.n_nodes) a.bvh_cache_nodes = a.n_nodes;
                 const dim3 bgrid((npix + BVH_BLOCK - 1) / BVH_BLOCK), bblock(BVH_BLOCK);
                 // PT_BVH_EXTRA_LDS=<bytes>: unused LDS per workgroup, to lower the waves per CU (occupancy experiment)
                 static const size_t bvh_extra_lds = getenv("PT_BVH_EXTRA_LDS") ? (size_t)atoi(getenv("PT_BVH_EXTRA_LDS")) : 0;
-                const size_t bsm = (size_t)a.bvh_cache_nodes * sizeof(float4) + bvh_extra_lds +
-                                   (size_t)(a.bvh_depth + 1) * BVH_BLOCK * (s16 ? sizeof(uint16_t) : sizeof(int));
+                const size_t bsm = bvh_extra_lds + (size_t)(a.bvh_depth + 2) * BVH_BLOCK * (s16 ? sizeof(uint16_t) : sizeof(int));
                 const bool r32 = a.bvh_geom32 != nullptr;          // the compact records (pt_scene_upload decides)
 #define PT_BVH_LAUNCH(SP, ST) do { if (r32) hipLaunchKernelGGL((trace_bvh_kernel<SP, ST, true>), bgrid, bblock, bsm, s, a); \
                                    else     hipLaunchKernelGGL((trace_bvh_kernel<SP, ST, false>), bgrid, bblock, bsm, s, a); } while (0)

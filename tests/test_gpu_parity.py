@@ -664,26 +664,6 @@ def test_spatial_index_with_coincident_and_degenerate_disks(pa):
     assert not np.isin(res[0][2], [60, 61, 62]).any()       # a duplicate never wins over object 5
 
 
-def test_spatial_index_with_its_top_levels_in_lds(pa, monkeypatch):
-    """PT_BVH_CACHE_NODES (an A/B switch, off by default: DESIGN.md 3.4) keeps the first nodes of the level-ordered
-    tree in LDS; the walk must find exactly what it finds without it."""
-    objs = pa.random_disk_scene(1025, 10)
-    P = pa.Params(96, 80, 500.0, 6, 5)
-    def render():
-        with pa.Renderer(P, objs, seed=2) as r:
-            r.trace(6)
-            return r.read_sum_f32(), r.segments, r.bvh_counters()
-    monkeypatch.delenv("PT_BVH_CACHE_NODES", raising=False)
-    a, sa, (na, ra) = render()
-    monkeypatch.setenv("PT_BVH_CACHE_NODES", "100")
-    b, sb, (nb, rb) = render()
-    assert sa == sb and ra == rb and 0 < nb < na          # same searches, same records, fewer node gathers
-    assert np.allclose(a, b, rtol=4e-6, atol=1e-6)         # (the order lanes finish in may differ: fp32 summation order)
-    with pa.Renderer(P, objs, seed=2, flags=pa.PT_FLAG_NO_BVH) as r:
-        r.trace(6)
-        assert r.segments == sa and r.bvh_counters() == (0, 0)
-
-
 def test_spatial_index_with_32_bit_stacks(pa, monkeypatch):
     """The walk's per-lane stack holds 16-bit node numbers while the tree has fewer than 65,536 nodes (LDS per wave
     is what it saves); PT_BVH_STACK32 selects the 32-bit form that larger trees take.  Same walk, same result."""
