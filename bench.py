@@ -42,7 +42,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP32_VALU_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (vector)"
-GATHER_PEAK_GBS = 8216.0           # fully divergent 16-byte gathers, measured: tools/ubench_gather.hip, profiles/r02_bvh_roofline.txt
+GATHER_PEAK_GBS = 15980.0          # fully divergent 16-byte gathers from an L1-resident (16-KB) table, measured: 999 G lane-gathers/s,
+                                   # tools/ubench_gather.hip, profiles/r03_bvh_walk.txt (round 2's 8,216 came from a 64-KB table, which
+                                   # does not fit the 32-KB L1; an L2-resident table gives 280 G distinct records/s = 4.5 TB/s)
 
 
 def flops_per_segment(objs):
@@ -554,12 +556,15 @@ def main():
                                  "157.3 TFLOP/s (= the fp32 MFMA peak)"},
         }
         if indexed:
-            # trace_bvh_kernel is bound by its per-lane 16-byte gathers (one per index node visited, three per
-            # object record), served by the CU's address unit and L1/L2 -- not by HBM, VALU or MFMA.  Algorithmic
-            # bytes per launch = 16 B x the gathers the kernel counted (pt_bvh_counters); peak = the rate of fully
-            # divergent 16-byte gathers measured on MI355X by tools/ubench_gather.hip (profiles/r02_bvh_roofline.txt:
-            # 513.5 G gathers/s = 8,216 GB/s from an L1-resident table; 267-282 G/s = 4.3-4.5 TB/s once the table
-            # only fits L2 -- the kernel's hot top levels sit in between).
+            # trace_bvh_kernel's memory side is per-lane 16-byte gathers (one per index node visited, two or three per
+            # object record), served by the CU's address unit and L1/L2 -- not HBM, not MFMA.  Algorithmic bytes per
+            # launch = 16 B x the gathers the kernel counted (pt_bvh_counters); peak = the rate of fully divergent
+            # 16-byte gathers measured on MI355X by tools/ubench_gather.hip (profiles/r03_bvh_walk.txt: 999 G
+            # lane-gathers/s = 15,980 GB/s from an L1-resident table, 280 G distinct records/s = 4.5 TB/s from an
+            # L2-resident one; the index's hot top levels sit in L1, ~90 % of its gathers hit there).  Since round 3
+            # the kernel is bound by VALU issue under divergence (0.24 wave-instructions per cycle per SIMD of mostly
+            # 4-cycle forms, half of the lanes active: profiles/r03_m_bvh_pmc_summary.txt), so frac says how far the
+            # gather path is from ITS limit, not how far the kernel is from its own.
             nodes, recs = r.bvh_counters()
             pad = r.bvh_padding_gathers()               # the empty slot of odd leaves: fetched, not algorithmic
             fetched = (nodes + recs) / max(launches, 1)
@@ -575,11 +580,12 @@ def main():
                                "padding_gathers_per_segment": round(pad / max(launches, 1) / max(segs_launch_rank0, 1), 2),
                                "fetched_gb_per_s": round(fetched * 16 / (kern_ms * 1e-3) / 1e9, 1),
                                "segments_per_launch": int(segs_launch_rank0),
-                               "note": "divergent 16-byte per-lane gathers (index nodes and object records) bound this "
-                                       "kernel; algorithmic bytes = 16 B x gathers counted by the kernel "
+                               "note": "memory side: divergent 16-byte per-lane gathers (index nodes and object records); the "
+                                       "kernel itself is bound by VALU issue under divergence (DESIGN.md 3.4, round 3); "
+                                       "algorithmic bytes = 16 B x gathers counted by the kernel "
                                        "(pt_bvh_counters) without the empty slot that leaves with an odd number of "
                                        "objects fetch (pt_bvh_padding_gathers; fetched_gb_per_s includes it); peak = measured rate of such gathers from an L1-resident "
-                                       "table (tools/ubench_gather.hip, profiles/r02_bvh_roofline.txt); the linear-scan "
+                                       "16-KB table (tools/ubench_gather.hip, profiles/r03_bvh_walk.txt); the linear-scan "
                                        "flop formula of SURVEY 8d does not describe an indexed search"}
         if args.scene != "default":
             out["metric"] = "Mrays/s (samples x bounces)"

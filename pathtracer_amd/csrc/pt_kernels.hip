@@ -669,7 +669,7 @@ constexpr int BVH_BLOCK = 64;
 #define PT_BVH_ROUND_VISITS 8
 #endif
 #ifndef PT_BVH_SHADE_LANES
-#define PT_BVH_SHADE_LANES 12
+#define PT_BVH_SHADE_LANES 16
 #endif
 
 // REC32: the compact object records (TraceArgs::bvh_geom32) -- two 16-byte gathers per record instead of three; an

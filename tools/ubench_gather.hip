@@ -13,9 +13,11 @@
 // lanes_on: a 64-bit mask of the lanes that gather (the others sit the loop out under exec, as the lanes of a walk that
 // have finished or hold a leaf do): does a gather instruction cost by its active lanes or by the instruction?
 __global__ __launch_bounds__(64) void gather_kernel(const float4 *__restrict__ table, uint32_t mask, int iters, float *sink,
-                                                    unsigned long long lanes_on)
+                                                    unsigned long long lanes_on, int share)
 {
-    uint32_t x = (blockIdx.x * 64u + threadIdx.x) * 2654435761u + 12345u;
+    // share: groups of `share` neighbouring lanes read the same record (the lanes of a wave that stand at the same node
+    // of the index: all of them at the root, fewer and fewer further down)
+    uint32_t x = (blockIdx.x * 64u + threadIdx.x / (unsigned)share) * 2654435761u + 12345u;
     float acc = 0.f;
     if ((lanes_on >> (threadIdx.x & 63)) & 1ull)
     for (int it = 0; it < iters; ++it) {
@@ -51,12 +53,12 @@ int main(int argc, char **argv)
         for (const Pat &pt : pats)
         for (int w : {6, 8}) {
             const int grid = simds * w * rounds, iters = 4000 / rounds;
-            hipLaunchKernelGGL(gather_kernel, dim3(grid), dim3(64), 0, 0, table, (uint32_t)(n - 1), iters / 4, sink, pt.m);
+            hipLaunchKernelGGL(gather_kernel, dim3(grid), dim3(64), 0, 0, table, (uint32_t)(n - 1), iters / 4, sink, pt.m, 1);
             CK(hipDeviceSynchronize());
             float best = 1e30f;
             for (int rep = 0; rep < 3; ++rep) {
                 CK(hipEventRecord(e0, 0));
-                hipLaunchKernelGGL(gather_kernel, dim3(grid), dim3(64), 0, 0, table, (uint32_t)(n - 1), iters, sink, pt.m);
+                hipLaunchKernelGGL(gather_kernel, dim3(grid), dim3(64), 0, 0, table, (uint32_t)(n - 1), iters, sink, pt.m, 1);
                 CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
                 float ms; CK(hipEventElapsedTime(&ms, e0, e1));
                 if (ms < best) best = ms;
@@ -65,6 +67,21 @@ int main(int argc, char **argv)
             printf("table %5d KB  %-15s %d waves/SIMD  %7.3f ms  %7.1f G lane-gathers/s = %6.2f TB/s;  %6.2f G wave-instructions/s = %5.1f cycles per instruction per CU at 2.4 GHz\n",
                    kb, pt.name, w, best, gathers / best / 1e6, gathers * 16 / best / 1e9, instrs / best / 1e6,
                    2.4e9 * p.multiProcessorCount / (instrs / (best * 1e-3)));
+        }
+        // lanes that share a record: does the cache look a line up once per lane or once per distinct line?
+        for (int share : {2, 4, 16, 64}) {
+            const int w = 8, grid = simds * w * rounds, iters = 4000 / rounds;
+            float best = 1e30f;
+            for (int rep = 0; rep < 4; ++rep) {
+                CK(hipEventRecord(e0, 0));
+                hipLaunchKernelGGL(gather_kernel, dim3(grid), dim3(64), 0, 0, table, (uint32_t)(n - 1), iters, sink, ~0ull, share);
+                CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+                float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+                if (rep && ms < best) best = ms;
+            }
+            const double gathers = (double)grid * 64 * iters * 4;
+            printf("table %5d KB  all 64 lanes, groups of %2d lanes read one record  %d waves/SIMD  %7.3f ms  %7.1f G lane-gathers/s = %6.2f TB/s (%5.1f G distinct records/s)\n",
+                   kb, share, w, best, gathers / best / 1e6, gathers * 16 / best / 1e9, gathers / share / best / 1e6);
         }
         CK(hipFree(table));
     }
