@@ -260,6 +260,15 @@ int pt_dev_specular(pt_ctx *ctx, int32_t n, const float *vector, const float *no
                     const float *u, float noise, float *out);
 int pt_dev_distance(pt_ctx *ctx, int32_t n, const pt_object *obj, const float *origin,
                     const float *vector, float *t_out);
+/* The spatial index's box test (an extension: the reference's closestObjectTo is a
+ * linear scan, src/Lib.hs:81-98) on `n` caller-supplied boxes and rays: box k =
+ * boxes[6k..6k+2] (lo) and [6k+3..6k+5] (hi) is encoded as pt_scene_upload encodes
+ * a node's box (padded by `pad`, centre and half-extent in binary16) and tested
+ * on the device against the ray (origin, vector) up to t_best[k]; out[k] = 1
+ * where the walk would enter the box.  The index only prunes, so the property
+ * to hold is one-sided: never 0 where the exact segment touches the box. */
+int pt_dev_box_test(pt_ctx *ctx, int32_t n, const double *boxes, double pad, const float *origin,
+                    const float *vector, const float *t_best, uint8_t *out);
 /* Philox2x32-10 on the device for ctr=(c0[k], c1[k]), key: out[2k], out[2k+1]. */
 int pt_dev_philox(pt_ctx *ctx, int32_t n, const uint32_t *c0, const uint32_t *c1,
                   uint32_t key, uint32_t *out);

@@ -85,6 +85,7 @@ SIGNATURES = {
     "pt_dev_diffuse": (C.c_int, [_P, C.c_int32, _P, _P, _P]),
     "pt_dev_specular": (C.c_int, [_P, C.c_int32, _P, _P, _P, C.c_float, _P]),
     "pt_dev_distance": (C.c_int, [_P, C.c_int32, C.POINTER(pt_object), _P, _P, _P]),
+    "pt_dev_box_test": (C.c_int, [_P, C.c_int32, _P, C.c_double, _P, _P, _P, _P]),
     "pt_dev_philox": (C.c_int, [_P, C.c_int32, _P, _P, C.c_uint32, _P]),
     "pt_scene_specialise": (C.c_int, [_P]),
     "pt_jit_info": (C.c_int, [_P, C.c_char_p, C.c_size_t]),

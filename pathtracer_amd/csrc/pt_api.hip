@@ -886,6 +886,31 @@ int pt_dev_distance(pt_ctx *c, int32_t n, const pt_object *obj, const float *ori
     return PT_OK;
 }
 
+int pt_dev_box_test(pt_ctx *c, int32_t n, const double *boxes, double pad, const float *origin, const float *vector,
+                    const float *t_best, uint8_t *out)
+{
+    if (c && c->group) c = group_first(c);
+    if (int s = check_ctx(c)) return s;
+    if (n < 1 || !boxes || !origin || !vector || !t_best || !out || !(pad >= 0.0))
+        return fail(c, PT_ERR_INVALID, "pt_dev_box_test: bad argument");
+    std::vector<BvhNode> nodes((size_t)n);
+    for (int k = 0; k < n; ++k) {                            // encoded as pt_scene_upload's builder encodes a node's box
+        BvhBox b;
+        for (int a = 0; a < 3; ++a) { b.lo[a] = boxes[6 * (size_t)k + a]; b.hi[a] = boxes[6 * (size_t)k + 3 + a]; }
+        bvh_encode_box(b, pad, nodes[(size_t)k].h);
+        nodes[(size_t)k].code = 0;
+    }
+    DevBuf<float4> dn; DevBuf<float> dorg, dv, dt; DevBuf<uint8_t> dout;
+    PT_HIP(c, dn.alloc((size_t)n)); PT_HIP(c, dorg.alloc((size_t)n * 3)); PT_HIP(c, dv.alloc((size_t)n * 3));
+    PT_HIP(c, dt.alloc((size_t)n)); PT_HIP(c, dout.alloc((size_t)n));
+    PT_HIP(c, dn.up(reinterpret_cast<const float4 *>(nodes.data()), (size_t)n));
+    PT_HIP(c, dorg.up(origin, (size_t)n * 3)); PT_HIP(c, dv.up(vector, (size_t)n * 3)); PT_HIP(c, dt.up(t_best, (size_t)n));
+    PT_HIP(c, launch_dev_box(n, dn.p, dorg.p, dv.p, dt.p, dout.p, c->stream));
+    PT_HIP(c, hipStreamSynchronize(c->stream));
+    PT_HIP(c, dout.down(out, (size_t)n));
+    return PT_OK;
+}
+
 int pt_dev_philox(pt_ctx *c, int32_t n, const uint32_t *c0, const uint32_t *c1, uint32_t key, uint32_t *out)
 {
     if (c && c->group) c = group_first(c);

@@ -96,6 +96,22 @@ struct Bvh {
 
 struct BvhBox { double lo[3], hi[3]; };
 
+// a box as a node holds it: pad, widen by fp32 rounding, then the centre as a binary16 and the half-extent rounded UP to
+// cover both sides from that centre -- the device's test is plain fp32 on these values (slab_hit, pt_device.hpp)
+inline void bvh_encode_box(const BvhBox &bb, double pad, uint16_t h[6])
+{
+    for (int a = 0; a < 3; ++a) {
+        const float lo = (float)(bb.lo[a] - pad) - std::fabs((float)(bb.lo[a] - pad)) * 1e-7f;
+        const float hi = (float)(bb.hi[a] + pad) + std::fabs((float)(bb.hi[a] + pad)) * 1e-7f;
+        uint16_t ch = half_round_dir(0.5f * lo + 0.5f * hi, false);
+        if ((ch & 0x7fffu) >= 0x7c00u) ch = (uint16_t)((ch & 0x8000u) | 0x7bffu);     // keep the centre finite
+        const double c = (double)half_bits_to_float(ch);
+        const double ext = std::max((double)hi - c, c - (double)lo);
+        h[a]     = ch;
+        h[3 + a] = half_round_dir((float)(ext * (1.0 + 2e-7)) + 1e-30f, true);
+    }
+}
+
 // centre, unit normal, radius of a Disk -> axis-aligned bounds
 inline BvhBox disk_bounds(const double c[3], const double nhat[3], double r)
 {
@@ -168,18 +184,7 @@ private:
     {
         const BvhBox bb = bounds(b, e);
         BvhNode n;
-        for (int a = 0; a < 3; ++a) {
-            // pad, widen by fp32 rounding, then centre to nearest binary16 and the half-extent rounded up to cover
-            // both sides from that centre: the device's test is plain fp32 on these values
-            const float lo = (float)(bb.lo[a] - pad_) - std::fabs((float)(bb.lo[a] - pad_)) * 1e-7f;
-            const float hi = (float)(bb.hi[a] + pad_) + std::fabs((float)(bb.hi[a] + pad_)) * 1e-7f;
-            uint16_t ch = half_round_dir(0.5f * lo + 0.5f * hi, false);
-            if ((ch & 0x7fffu) >= 0x7c00u) ch = (uint16_t)((ch & 0x8000u) | 0x7bffu);     // keep the centre finite
-            const double c = (double)half_bits_to_float(ch);
-            const double ext = std::max((double)hi - c, c - (double)lo);
-            n.h[a]     = ch;
-            n.h[3 + a] = half_round_dir((float)(ext * (1.0 + 2e-7)) + 1e-30f, true);
-        }
+        bvh_encode_box(bb, pad_, n.h);
         const int cnt = e - b;
         if (cnt <= BVH_LEAF_MAX) {
             n.code = ~(((prim_base_ + b) << 3) | (cnt - 1));

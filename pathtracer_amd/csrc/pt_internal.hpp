@@ -92,6 +92,7 @@ hipError_t launch_dev_specular(int n, const float *v, const float *nrm, const fl
                                float noise_rev, float *out, hipStream_t s);
 hipError_t launch_dev_distance(int n, const float4 *geom1_rect, const float *o, const float *v,
                                float *t, hipStream_t s);
+hipError_t launch_dev_box(int n, const float4 *nodes, const float *o, const float *v, const float *t_best, uint8_t *out, hipStream_t s);
 hipError_t launch_dev_philox(int n, const uint32_t *c0, const uint32_t *c1, uint32_t key,
                              uint32_t *out, hipStream_t s);
 #endif

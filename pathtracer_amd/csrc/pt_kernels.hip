@@ -1279,6 +1279,22 @@ __global__ void dev_philox_kernel(int n, const uint32_t *__restrict__ c0, const 
     out[2 * k] = a; out[2 * k + 1] = b;
 }
 
+// the spatial index's box test (slab_hit) on caller-supplied nodes and rays: out[k] = 1 where the walk would enter the box
+__global__ void dev_box_kernel(int n, const float4 *__restrict__ nodes, const float *__restrict__ o, const float *__restrict__ v,
+                               const float *__restrict__ t_best, uint8_t *__restrict__ out)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const SlabRay sr = slab_ray(v[3 * k], v[3 * k + 1], v[3 * k + 2]);
+    out[k] = slab_hit(nodes[k], o[3 * k], o[3 * k + 1], o[3 * k + 2], sr, t_best[k]) ? 1 : 0;
+}
+
+hipError_t launch_dev_box(int n, const float4 *nodes, const float *o, const float *v, const float *t_best, uint8_t *out, hipStream_t s)
+{
+    hipLaunchKernelGGL(dev_box_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, nodes, o, v, t_best, out);
+    return hipGetLastError();
+}
+
 hipError_t launch_dev_diffuse(int n, const float4 *m, const float *u, float *out, hipStream_t s)
 {
     hipLaunchKernelGGL(dev_diffuse_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, m, u, out);

@@ -251,6 +251,18 @@ class Renderer:
                                   vector.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p)), self._ctx)
         return out
 
+    def dev_box_test(self, boxes, pad: float, origin, vector, t_best):
+        """The spatial index's box test on (n, 6) boxes (lo, hi), encoded as the builder encodes them."""
+        boxes = np.ascontiguousarray(boxes, dtype=np.float64)
+        origin = np.ascontiguousarray(origin, dtype=np.float32)
+        vector = np.ascontiguousarray(vector, dtype=np.float32)
+        t_best = np.ascontiguousarray(t_best, dtype=np.float32)
+        out = np.empty(len(boxes), dtype=np.uint8)
+        check(lib.pt_dev_box_test(self._ctx, len(boxes), boxes.ctypes.data_as(C.c_void_p), float(pad),
+                                  origin.ctypes.data_as(C.c_void_p), vector.ctypes.data_as(C.c_void_p),
+                                  t_best.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p)), self._ctx)
+        return out
+
     def dev_philox(self, c0, c1, key: int):
         c0 = np.ascontiguousarray(c0, dtype=np.uint32)
         c1 = np.ascontiguousarray(c1, dtype=np.uint32)

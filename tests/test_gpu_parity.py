@@ -757,3 +757,56 @@ def test_limit_of_65536_objects(pa):
     assert tr.segments.value - H * W * spp == segs - H * W   # the oracle also counts each sample's primary search
     bad = (np.abs(dev - ora) > 2e-4 * np.abs(ora) + 1e-5).any(axis=2).mean()
     assert bad <= 0.01
+
+
+def test_box_test_of_the_spatial_index_never_misses(pa, small):
+    """The index only prunes, so its box test (centre / half-extent nodes in binary16, nine v_fma_mix_f32: slab_hit,
+    DESIGN.md 3.4) may say "reached" too often but never too seldom: wherever the exact segment origin + t*vector,
+    0 <= t <= t_best, touches the UNPADDED box (fp64 slab test with exact handling of zero components), the device says
+    1.  Random rays and boxes, rays with zero direction components (a pixel of the middle row or column), origins on a
+    face, boxes of zero thickness, tiny and large scenes, origins twenty scene sizes away; the pad is the builder's 2e-5
+    of the scene's extent."""
+    rng = np.random.default_rng(11)
+    n = 40000
+    false_pos = []
+    for scale, offset, far in ((100.0, 0.0, 0.0), (1.0, 0.0, 0.0), (1e-3, 0.0, 0.0), (500.0, 2000.0, 0.0), (3e4, 0.0, 0.0), (100.0, 0.0, 20.0)):
+        c = offset + scale * (rng.random((n, 3)) - 0.5)
+        h = scale * 0.05 * rng.random((n, 3)) * (rng.random((n, 3)) > 0.1)          # a tenth of the sides: zero thickness
+        lo, hi = c - h, c + h
+        extent = np.abs(np.concatenate([lo, hi])).max()
+        pad = 2e-5 * extent + 1e-30
+        org = (offset + scale * (rng.random((n, 3)) - 0.5)).astype(np.float32)
+        if far:                                                                      # origins `far` scene sizes away (a hit on an infinite plane)
+            u = rng.standard_normal((n, 3))
+            org = (org + far * scale * u / np.linalg.norm(u, axis=1, keepdims=True)).astype(np.float32)
+        vec = rng.standard_normal((n, 3))
+        vec /= np.linalg.norm(vec, axis=1, keepdims=True)
+        vec[rng.random((n, 3)) < 0.08] = 0.0                                         # axis-parallel rays
+        vec[np.all(vec == 0.0, axis=1)] = (0.0, 0.0, 1.0)
+        vec = vec.astype(np.float32)
+        k = rng.random(n) < 0.15                                                     # origins exactly on a face
+        org[k, 0] = lo[k, 0].astype(np.float32)
+        aim = rng.random(n) < 0.5                                                    # half of the rays aimed at their box
+        tgt = (c + h * (rng.random((n, 3)) - 0.5))[aim]
+        dv = tgt - org[aim].astype(np.float64)
+        vec[aim] = (dv / np.maximum(np.linalg.norm(dv, axis=1, keepdims=True), 1e-30)).astype(np.float32)
+        t_best = np.where(rng.random(n) < 0.3, np.inf, scale * 2.0 * rng.random(n)).astype(np.float32)
+        dev = small.dev_box_test(np.concatenate([lo, hi], axis=1), pad, org, vec, t_best)
+        # exact: intersect [0, t_best] with the three slabs of the unpadded box, in fp64 on the fp32 ray
+        o64, v64 = org.astype(np.float64), vec.astype(np.float64)
+        tn = np.zeros(n); tf = t_best.astype(np.float64).copy()
+        ok = np.ones(n, dtype=bool)
+        for a in range(3):
+            z = v64[:, a] == 0.0
+            ok &= ~z | ((o64[:, a] >= lo[:, a]) & (o64[:, a] <= hi[:, a]))
+            with np.errstate(divide="ignore", invalid="ignore"):
+                t0 = (lo[:, a] - o64[:, a]) / v64[:, a]
+                t1 = (hi[:, a] - o64[:, a]) / v64[:, a]
+            tn = np.where(z, tn, np.maximum(tn, np.minimum(t0, t1)))
+            tf = np.where(z, tf, np.minimum(tf, np.maximum(t0, t1)))
+        exact = ok & (tn <= tf)
+        missed = exact & (dev == 0)
+        assert not missed.any(), (scale, offset, int(missed.sum()), np.flatnonzero(missed)[:5])
+        assert exact.sum() > n // 8                                                   # the case is exercised
+        false_pos.append(float(((dev == 1) & ~exact).sum()) / n)
+    assert max(false_pos) < 0.05, false_pos                                           # and the test still prunes
