@@ -863,10 +863,13 @@ __global__ __launch_bounds__(BVH_BLOCK) void trace_bvh_kernel(TraceArgs a)
                     }
                 }
             }
-            if (ready) {
-                if (want && needy) {                       // the pool is dry: this lane is done
-                    live = false; ready = false;
-                } else {
+            // (one flat region for the lanes that go on: nested, every level of the nest cost a copy of each state
+            // register -- 42 v_mov_b32 per shade step)
+            const bool lane_done = ready && want && needy; // the pool is dry: this lane is done
+            const bool go_on = ready && !lane_done;
+            if (lane_done) { live = false; ready = false; }
+            {
+                if (go_on) {
                     const bool restart = want;             // a new sample from the (current) pixel's primary hit,
                     if (restart) gs = a.sample_begin + sn * a.sample_stride;
                     // whose constants live in LDS, not in registers: the walk needs the registers (occupancy)
