@@ -293,7 +293,9 @@ int pt_dev_philox(pt_ctx *ctx, int32_t n, const uint32_t *c0, const uint32_t *c1
  * the files.  Applies to scenes of <= 16 objects on the default flags (for 9-16
  * objects, whose list the general path streams through the scalar cache, the
  * scene kernel is the only by-value kernel: measured 2.3x the streamed rate);
- * the kernel is dropped by the next pt_scene_upload.  On PT_ERR_UNSUPPORTED (no libhiprtc on the machine, a scene
+ * the kernel is dropped by the next pt_scene_upload.  A kernel shipped with the
+ * library for this scene (pt_scene_kernel_ship) is used before any compiler is
+ * looked for.  On PT_ERR_UNSUPPORTED (no libhiprtc on the machine, a scene
  * or flags it does not cover) the context keeps using the general kernel.
  * PT_SPECIALISE=1 in the environment makes pt_scene_upload do this for every
  * scene it applies to (failures ignored). */
@@ -309,6 +311,24 @@ int pt_jit_info(pt_ctx *ctx, char *buf, size_t size);
  * user has gone (the next one skips the compile), and is unloaded once more
  * than 16 unused ones have piled up, least recently used first. */
 int pt_jit_cache_size(void);
+/* Build support, no GPU needed: scene kernels SHIPPED with the library.  The
+ * reference's scene is a constant of the program (src/Object.hs:147-148), so
+ * its kernel can be compiled when the library is built and found by
+ * pt_scene_specialise without libhiprtc and without the compile: files in
+ * <directory of libpt.so>/scene_kernels/, in the format of the kernel cache
+ * (each spells out source, geometry and target and is used only where all of
+ * it matches; the compiler is not part of the key -- the file is the build's
+ * own artefact).  With source_out, writes the kernel source of the scene
+ * `objs` to that file (compile it with the Makefile's flags and -I csrc); with
+ * code_in, stores the code object compiled from it for target `arch` (the
+ * --offload-arch value, e.g. "gfx950:sramecc+:xnack-") in that directory.
+ * `make scene_kernels` / tools/build_scene_kernels.py do both for the default
+ * scene.  With neither, a query: PT_OK if a kernel for this scene and target is
+ * shipped, PT_ERR_UNSUPPORTED if not.  PT_SHIPPED_KERNELS=off in the environment
+ * ignores the directory; PT_NO_HIPRTC=1 keeps pt_scene_specialise from loading a
+ * compiler (shipped kernels only). */
+int pt_scene_kernel_ship(const pt_object *objs, int32_t n, const char *arch,
+                         const char *source_out, const char *code_in);
 
 /* Last kernel's launch duration in milliseconds, measured with HIP events on
  * the context's stream around the most recent pt_trace (all its launches).

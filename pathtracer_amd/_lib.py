@@ -90,6 +90,7 @@ SIGNATURES = {
     "pt_scene_specialise": (C.c_int, [_P]),
     "pt_jit_info": (C.c_int, [_P, C.c_char_p, C.c_size_t]),
     "pt_jit_cache_size": (C.c_int, []),
+    "pt_scene_kernel_ship": (C.c_int, [C.POINTER(pt_object), C.c_int32, C.c_char_p, C.c_char_p, C.c_char_p]),
     "pt_set_timing": (C.c_int, [_P, C.c_int32]),
     "pt_last_trace_ms": (C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_int32)]),
     "pt_create_multi": (C.c_int, [C.POINTER(_P), C.POINTER(pt_params), C.POINTER(C.c_int32), C.c_int32]),

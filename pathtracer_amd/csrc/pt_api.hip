@@ -545,6 +545,28 @@ int pt_scene_specialise(pt_ctx *c)
     return PT_OK;
 }
 
+int pt_scene_kernel_ship(const pt_object *objs, int32_t n, const char *arch, const char *source_out, const char *code_in)
+{
+    if (!objs || n < 1 || n > MAX_JIT_OBJECTS || !arch) return PT_ERR_INVALID;
+    std::vector<float4> geom((size_t)n * 3), mat((size_t)n * 4), rect((size_t)n * 2);
+    std::vector<double> prim((size_t)n * PRIM_DOUBLES);
+    bool spec = false;
+    for (int k = 0; k < n; ++k) {
+        if (objs[k].kind != PT_INFINITE_PLANE && objs[k].kind != PT_DISK && objs[k].kind != PT_SPHERE && objs[k].kind != PT_RECTANGLE)
+            return PT_ERR_INVALID;
+        flatten_object(objs[k], &geom[(size_t)k * 3], &mat[(size_t)k * 4], &prim[(size_t)k * PRIM_DOUBLES], &rect[(size_t)k * 2]);
+        spec = spec || (objs[k].reflective && !(objs[k].emittance > 0.0)) || objs[k].kind == PT_SPHERE ||
+               objs[k].kind == PT_RECTANGLE;                     // pt_scene_upload's rule for the general-scatter kernels
+    }
+    std::string why;
+    const int rc = jit_ship(n, spec, geom.data(), arch, source_out, code_in, why);
+    if (rc < 0) {
+        std::fprintf(stderr, "pt_scene_kernel_ship: %s\n", why.c_str());
+        return PT_ERR_INVALID;
+    }
+    return rc == 0 ? PT_OK : PT_ERR_UNSUPPORTED;             // (the query form: no such kernel shipped)
+}
+
 int pt_jit_cache_size(void) { return jit_cache_size(); }
 
 int pt_jit_info(pt_ctx *c, char *buf, size_t size)

@@ -108,6 +108,8 @@ hipFunction_t jit_static_kernel(int device, int n_obj, bool spec, const float4 *
 std::string jit_kernel_info(hipFunction_t fn);
 // A context that stops using a kernel from jit_static_kernel (scene change, pt_destroy) gives it back -- after its
 // stream has drained.  Unused kernels beyond a small number are unloaded.
+int jit_ship(int n_obj, bool spec, const float4 *geom_host, const char *arch, const char *src_out, const char *code_in,
+             std::string &err);
 void jit_release(hipFunction_t fn);
 int jit_cache_size();
 #endif

@@ -161,6 +161,69 @@ void disk_cache_store(const std::string &dir, const std::string &material, const
     if (!ok || !closed || std::rename(tmp.c_str(), final_name.c_str()) != 0) (void)std::remove(tmp.c_str());
 }
 
+// ---- scene kernels shipped with the library -----------------------------------------------------------------------
+// The reference's scene is a constant of the program (src/Object.hs:147-148), so its kernel can be compiled when the
+// library is built, by hipcc, and a host on a machine without libhiprtc -- or one that must not spend 0.7 s in a
+// compiler at start-up -- still runs it.  `make scene_kernels` (tools/build_scene_kernels.py) asks the library for the
+// kernel source of a scene (pt_scene_kernel_ship below), compiles it offline with the Makefile's code-generation flags
+// and hands the code object back to be stored as <directory of libpt.so>/scene_kernels/<hash>.co in the format of the
+// on-disk cache: the file starts with everything the code depends on (source text, geometry bits, NS, SPEC, the
+// --offload-arch, the embedded headers) and is used only where that matches byte for byte -- a library rebuilt from
+// changed sources simply does not find its predecessor's files.  What is NOT part of the key is the compiler: the
+// file is this build's own artefact, like the kernels inside libpt.so.  PT_SHIPPED_KERNELS=off ignores the directory.
+std::string shipped_dir()
+{
+    if (const char *e = getenv("PT_SHIPPED_KERNELS")) {
+        const std::string v = e;
+        if (v.empty() || v == "0" || v == "off") return std::string();
+    }
+    Dl_info di{};
+    if (dladdr((void *)&shipped_dir, &di) == 0 || !di.dli_fname) return std::string();
+    const std::string lib = di.dli_fname;
+    const size_t slash = lib.find_last_of('/');
+    return (slash == std::string::npos ? std::string(".") : lib.substr(0, slash)) + "/scene_kernels";
+}
+
+// the geometry exactly as launch_trace_ns pads it, and the kernel's source text for it
+int scene_kernel_ns(int n_obj) { return n_obj <= 4 ? 4 : n_obj <= MAX_STATIC_OBJECTS ? MAX_STATIC_OBJECTS : MAX_JIT_OBJECTS; }
+
+std::vector<float> padded_geometry(int NS, int n_obj, const float4 *geom_host)
+{
+    std::vector<float> g((size_t)NS * 12, 0.0f);
+    for (int k = 0; k < NS; ++k) {
+        if (k < n_obj) std::memcpy(&g[(size_t)k * 12], &geom_host[3 * k], 12 * sizeof(float));
+        else g[(size_t)k * 12 + 7] = __builtin_inff();
+    }
+    return g;
+}
+
+std::string scene_kernel_source(int NS, bool spec, const std::vector<float> &g)
+{
+    std::string src = "#define PT_JIT 1\n#define PT_JIT_NS " + std::to_string(NS) + "\n#define PT_JIT_SPEC " +
+                      (spec ? "1" : "0") + "\n#define PT_JIT_F(x) __builtin_bit_cast(float, x)\n#define PT_JIT_GEOM {";
+    for (int k = 0; k < NS; ++k) {
+        src += k ? ",{" : "{";
+        for (int i = 0; i < 12; ++i) {
+            uint32_t bits;
+            std::memcpy(&bits, &g[(size_t)k * 12 + i], 4);
+            char buf[32];
+            std::snprintf(buf, sizeof buf, "%sPT_JIT_F(0x%08xu)", i ? "," : "", bits);
+            src += buf;
+        }
+        src += "}";
+    }
+    src += "}\n#include \"pt_static_kernel.hpp\"\n"
+           // which form lane_of()/pick() took in this compilation (pt_static_kernel.hpp), for pt_jit_info
+           "extern \"C\" __device__ __attribute__((used)) int pt_jit_has_inverse_ballot = "
+           "__has_builtin(__builtin_amdgcn_inverse_ballot_w64) ? 1 : 0;\n";
+    return src;
+}
+
+std::string shipped_material(const std::string &src, const std::string &arch)
+{
+    return src + "\n//" + arch + "\n//shipped with the library\n" + src_pt_static_kernel_hpp + src_pt_internal_hpp + src_pt_device_hpp;
+}
+
 struct Entry {
     hipModule_t mod = nullptr; hipFunction_t fn = nullptr; std::string info;
     int device = 0;
@@ -196,13 +259,8 @@ void evict_unused_locked()
 hipFunction_t jit_static_kernel(int device, int n_obj, bool spec, const float4 *geom_host, std::string &err)
 {
     if (n_obj < 0 || n_obj > MAX_JIT_OBJECTS) { err = "more objects than a scene kernel takes"; return nullptr; }
-    const int NS = n_obj <= 4 ? 4 : n_obj <= MAX_STATIC_OBJECTS ? MAX_STATIC_OBJECTS : MAX_JIT_OBJECTS;
-    // the geometry exactly as launch_trace_ns pads it
-    std::vector<float> g((size_t)NS * 12, 0.0f);
-    for (int k = 0; k < NS; ++k) {
-        if (k < n_obj) std::memcpy(&g[(size_t)k * 12], &geom_host[3 * k], 12 * sizeof(float));
-        else g[(size_t)k * 12 + 7] = __builtin_inff();
-    }
+    const int NS = scene_kernel_ns(n_obj);
+    const std::vector<float> g = padded_geometry(NS, n_obj, geom_host);
     std::string key((const char *)g.data(), g.size() * sizeof(float));
     key += (char)NS; key += (char)(spec ? 1 : 0); key += (char)device;
     if (const char *e = getenv("PT_JIT_FLAGS")) key += e;
@@ -230,29 +288,18 @@ hipFunction_t jit_static_kernel(int device, int n_obj, bool spec, const float4 *
         if (code.empty()) { err = std::string("PT_SCENE_KERNEL_CO: cannot read ") + co; return nullptr; }
     }
 #endif
-    bool from_disk = false;
+    bool from_disk = false, shipped = false;
     std::string material;                                  // everything the code object depends on (disk cache)
     const std::string cache_dir = disk_cache_dir();
-    if (code.empty()) {
-    if (!r.ok) { err = "libhiprtc.so not found or incomplete"; return nullptr; }
-
-    std::string src = "#define PT_JIT 1\n#define PT_JIT_NS " + std::to_string(NS) + "\n#define PT_JIT_SPEC " +
-                      (spec ? "1" : "0") + "\n#define PT_JIT_F(x) __builtin_bit_cast(float, x)\n#define PT_JIT_GEOM {";
-    for (int k = 0; k < NS; ++k) {
-        src += k ? ",{" : "{";
-        for (int i = 0; i < 12; ++i) {
-            uint32_t bits;
-            std::memcpy(&bits, &g[(size_t)k * 12 + i], 4);
-            char buf[32];
-            std::snprintf(buf, sizeof buf, "%sPT_JIT_F(0x%08xu)", i ? "," : "", bits);
-            src += buf;
-        }
-        src += "}";
+    const std::string src = scene_kernel_source(NS, spec, g);
+    const std::string ship_dir = shipped_dir();
+    if (code.empty() && !getenv("PT_JIT_FLAGS")) {         // a kernel built with this library (make scene_kernels)?
+        material = shipped_material(src, arch);
+        shipped = disk_cache_load(ship_dir, material, code);
     }
-    src += "}\n#include \"pt_static_kernel.hpp\"\n"
-           // which form lane_of()/pick() took in this compilation (pt_static_kernel.hpp), for pt_jit_info
-           "extern \"C\" __device__ __attribute__((used)) int pt_jit_has_inverse_ballot = "
-           "__has_builtin(__builtin_amdgcn_inverse_ballot_w64) ? 1 : 0;\n";
+    if (code.empty()) {
+    // (PT_NO_HIPRTC in the environment: a host that must not load a compiler, and the tests of the shipped kernels)
+    if (!r.ok || getenv("PT_NO_HIPRTC")) { err = "libhiprtc.so not found, incomplete or not wanted (PT_NO_HIPRTC), and no kernel for this scene was shipped with the library"; return nullptr; }
 
     const char *headers[] = {src_pt_static_kernel_hpp, src_pt_internal_hpp, src_pt_device_hpp};
     const char *names[] = {"pt_static_kernel.hpp", "pt_internal.hpp", "pt_device.hpp"};
@@ -296,7 +343,7 @@ hipFunction_t jit_static_kernel(int device, int n_obj, bool spec, const float4 *
     hipError_t he = hipModuleLoadData(&e.mod, code.data());
     if (he != hipSuccess) {
         (void)hipGetLastError();
-        err = std::string("hipModuleLoadData: ") + hipGetErrorString(he);
+        err = std::string("hipModuleLoadData: ") + hipGetErrorString(he) + (shipped ? " (a kernel shipped in " + ship_dir + ")" : std::string());
         if (from_disk) (void)std::remove((cache_dir + "/" + disk_cache_name(material)).c_str());   // a file that does not load is not kept
         return nullptr;
     }
@@ -316,13 +363,49 @@ hipFunction_t jit_static_kernel(int device, int n_obj, bool spec, const float4 *
         }
         (void)hipGetLastError();
     }
-    e.info = r.where + ", " + arch + ", __builtin_amdgcn_inverse_ballot_w64 " +
+    e.info = (shipped ? "hipcc at build time (make scene_kernels)" : r.where) + ", " + arch + ", __builtin_amdgcn_inverse_ballot_w64 " +
              (has == 1 ? "available" : has == 0 ? "missing (v_cndmask_b32 form)" : "unknown") +
-             (from_disk ? ", code object from the on-disk cache " + cache_dir : ", compiled in this process");
+             (shipped ? ", code object shipped with the library in " + ship_dir
+                      : from_disk ? ", code object from the on-disk cache " + cache_dir : ", compiled in this process");
     e.device = device; e.users = 1; e.stamp = ++g_clock;
     g_cache.emplace(std::move(key), e);
     evict_unused_locked();
     return e.fn;
+}
+
+// Build support (pt_scene_kernel_ship, include/pt.h): the kernel source of a scene to a file, and a code object
+// compiled from it into the shipped directory.  No GPU and no HIP call.
+int jit_ship(int n_obj, bool spec, const float4 *geom_host, const char *arch, const char *src_out, const char *code_in,
+             std::string &err)
+{
+    if (n_obj < 0 || n_obj > MAX_JIT_OBJECTS) { err = "more objects than a scene kernel takes"; return -1; }
+    const int NS = scene_kernel_ns(n_obj);
+    const std::string src = scene_kernel_source(NS, spec, padded_geometry(NS, n_obj, geom_host));
+    if (src_out) {
+        FILE *f = std::fopen(src_out, "wb");
+        if (!f || std::fwrite(src.data(), 1, src.size(), f) != src.size() || std::fclose(f) != 0) { err = std::string("cannot write ") + src_out; return -1; }
+    }
+    if (!src_out && !code_in) {                            // query: is a kernel for this scene and target shipped?
+        std::vector<char> code;
+        return disk_cache_load(shipped_dir(), shipped_material(src, std::string("--offload-arch=") + arch), code) ? 0 : 1;
+    }
+    if (code_in) {
+        std::vector<char> code;
+        if (FILE *f = std::fopen(code_in, "rb")) {
+            char buf[65536];
+            size_t got;
+            while ((got = std::fread(buf, 1, sizeof buf, f)) > 0) code.insert(code.end(), buf, buf + got);
+            std::fclose(f);
+        }
+        if (code.empty()) { err = std::string("cannot read ") + code_in; return -1; }
+        const std::string dir = shipped_dir();
+        if (dir.empty()) { err = "no directory for shipped kernels (PT_SHIPPED_KERNELS=off?)"; return -1; }
+        const std::string material = shipped_material(src, std::string("--offload-arch=") + arch);
+        disk_cache_store(dir, material, code);
+        std::vector<char> back;
+        if (!disk_cache_load(dir, material, back) || back != code) { err = "could not store the kernel in " + dir; return -1; }
+    }
+    return 0;
 }
 
 void jit_release(hipFunction_t fn)

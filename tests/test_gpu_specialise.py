@@ -84,7 +84,7 @@ def test_scene_kernels_for_nine_to_sixteen_objects(pa, n):
     # sliced (>= 512 samples) and repeated launches through the scene kernel
     with pa.Renderer(P, objs, seed=3) as r:
         assert r.specialise(), r.last_error()
-        assert "hiprtc" in r.jit_info()
+        assert "hiprtc" in r.jit_info() or "hipcc at build time" in r.jit_info()
         r.trace(520); r.trace(8)
         c, sc = r.read_sum_f32(), r.segments
     with pa.Renderer(P, objs, seed=3) as r:
@@ -183,7 +183,7 @@ def test_scene_kernels_are_kept_on_disk(pa, tmp_path):
             "    print(json.dumps({'info': r.jit_info(), 'sha': hashlib.sha256(r.read_sum_f32().tobytes()).hexdigest()}))\n" % root)
 
     def run(scene, cache):
-        env = dict(os.environ, PT_KERNEL_CACHE=cache)
+        env = dict(os.environ, PT_KERNEL_CACHE=cache, PT_SHIPPED_KERNELS="off")     # (the default scene's kernel is also shipped with the library: not here)
         env.pop("PT_SPECIALISE", None)
         p = subprocess.run([sys.executable, "-c", prog, scene], env=env, capture_output=True, text=True, timeout=120)
         assert p.returncode == 0, p.stderr[-2000:]
@@ -208,3 +208,40 @@ def test_scene_kernels_are_kept_on_disk(pa, tmp_path):
     again = run("default", str(cache))
     assert "compiled in this process" in again["info"] and again["sha"] == first["sha"]
     assert path.read_bytes() == data or len(path.read_bytes()) == len(data)
+
+
+def test_default_scene_kernel_is_shipped_with_the_library(pa):
+    """`make scene_kernels` compiles the reference's constant scene (src/Object.hs:147-148) offline with hipcc and stores
+    the code object next to libpt.so (pt_scene_kernel_ship): a process that may not load a compiler (PT_NO_HIPRTC=1)
+    and has no kernel cache still gets the scene kernel for it -- the same canvas bit for bit as the general kernel --,
+    and for any other scene an honest PT_ERR_UNSUPPORTED; with the shipped directory ignored too, none at all."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prog = ("import sys, json, hashlib; sys.path.insert(0, %r)\n"
+            "import pathtracer_amd as pa\n"
+            "objs = pa.objects if sys.argv[1] == 'default' else pa.objects[:3]\n"
+            "with pa.Renderer(pa.Params(96, 80, 500.0, 1, 6), objs, seed=3) as r:\n"
+            "    r.trace(24); g = hashlib.sha256(r.read_sum_f32().tobytes()).hexdigest(); r.reset()\n"
+            "    ok = r.specialise(); err = r.last_error()\n"
+            "    r.trace(24)\n"
+            "    print(json.dumps({'ok': ok, 'err': err, 'info': r.jit_info(), 'general': g,\n"
+            "                      'sha': hashlib.sha256(r.read_sum_f32().tobytes()).hexdigest()}))\n" % root)
+
+    def run(scene, **extra):
+        env = dict(os.environ, PT_KERNEL_CACHE="off", PT_NO_HIPRTC="1", **extra)
+        env.pop("PT_SPECIALISE", None)
+        p = subprocess.run([sys.executable, "-c", prog, scene], env=env, capture_output=True, text=True, timeout=120)
+        assert p.returncode == 0, p.stderr[-2000:]
+        return json.loads(p.stdout.strip().splitlines()[-1])
+
+    a = run("default")
+    assert a["ok"] and "shipped with the library" in a["info"] and "hipcc at build time" in a["info"], a
+    assert a["sha"] == a["general"]                          # the same image as the general kernel, bit for bit
+    b = run("three planes")
+    assert not b["ok"] and b["info"] == "" and "no kernel for this scene was shipped" in b["err"], b
+    assert b["sha"] == b["general"]                          # the general kernel stayed in use
+    c = run("default", PT_SHIPPED_KERNELS="off")
+    assert not c["ok"] and c["info"] == "", c
