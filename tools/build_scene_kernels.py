@@ -39,7 +39,7 @@ def main():
         rc = lib.pt_scene_kernel_ship(objs, len(scene.objects), args.arch.encode(), None, co.encode())
         if rc != 0:
             sys.exit(f"pt_scene_kernel_ship(store) failed: {rc}")
-    print("shipped scene kernels:", sorted(os.listdir(d)))
+    print("shipped scene kernels:", sorted(f for f in os.listdir(d) if f.endswith(".co")))
 
 
 if __name__ == "__main__":
