@@ -466,7 +466,10 @@ int pt::trace_block(pt_ctx *c, int64_t k_begin, int32_t iters)
     // the by-value kernels: up to 8 objects, and up to 16 where a kernel has been compiled for the scene
     const bool static_path = (c->n_obj <= MAX_STATIC_OBJECTS || (c->scene_kernel && c->n_obj <= MAX_JIT_OBJECTS)) && reuse &&
                              !(c->p.flags & PT_FLAG_NO_STEAL);
-    if (!c->d_partial && iters >= SLICE_MIN_SAMPLES && static_path)
+    // (trace_bvh_kernel slices too: launch_trace's routing to it, restated)
+    const bool bvh_path = !static_path && c->n_obj > MAX_STATIC_OBJECTS && c->n_nodes > 0 && reuse &&
+                          !(c->p.flags & (PT_FLAG_NO_STEAL | PT_FLAG_LDS_TILES)) && !getenv("PT_BVH_LOCKSTEP");
+    if (!c->d_partial && ((iters >= SLICE_MIN_SAMPLES && static_path) || (iters >= BVH_SLICE_MIN_SAMPLES && bvh_path)))
         if (hipMalloc((void **)&c->d_partial, (size_t)(MAX_SLICES - 1) * npix(c) * 3 * sizeof(float)) != hipSuccess) {
             (void)hipGetLastError();                 // no memory for the planes: launches stay unsliced
             c->d_partial = nullptr;

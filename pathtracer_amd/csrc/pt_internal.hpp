@@ -21,8 +21,13 @@ template <int NS> struct StaticGeom {
 
 // Segment counter layout: SEG_LANES 64-bit counters per epoch, one per 128-byte line.
 constexpr int MAX_SLICES = 2;
-constexpr int SLICE_MIN_SAMPLES = 512;        // smaller launches are not sliced: the second set-up pass costs what the
+#ifndef PT_SLICE_MIN
+#define PT_SLICE_MIN 512
+#endif
+constexpr int SLICE_MIN_SAMPLES = PT_SLICE_MIN;        // smaller launches are not sliced: the second set-up pass costs what the
                                               // drain saves (and more when consecutive frames overlap: 256 spp +2 %, 128 spp +8 %)
+constexpr int BVH_SLICE_MIN_SAMPLES = 256;    // trace_bvh_kernel: its one-wave workgroups live longer per sample, so slicing pays earlier
+                                              // (4K, serial launches: 256 spp -5...7 %, 128 spp -3 %; pipelined frames 256 spp -0.4 %, 128 spp +2 %)
 constexpr int SEG_LANES = 64;
 constexpr int SEG_LANE_STRIDE = 16;                 // in counters (128 bytes)
 constexpr int SEG_EPOCH = SEG_LANES * SEG_LANE_STRIDE;

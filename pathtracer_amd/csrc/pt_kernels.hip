@@ -697,10 +697,17 @@ __global__ __launch_bounds__(BVH_BLOCK) void trace_bvh_kernel(TraceArgs a)
     const bool in_canvas = pixel0 + tid < npix;
     const int pc = in_canvas ? pixel0 + tid : 0;
     const int pi = pc / a.width, pj = pc - pi * a.width;
-    const uint32_t n = (uint32_t)a.n_samples;
+    // this workgroup's slice of the launch's samples (TraceArgs::slice_*, as in trace_static_kernel: a second, short
+    // slice dispatched behind the first leaves only short waves for the end of a long launch); slices beyond the first
+    // start their sums at 0 in a plane of their own, which slice_sum_kernel adds to the canvas
+    const int slice = blockIdx.y;
+    const uint32_t n = (uint32_t)(a.n_slices > 1 ? a.slice_n[slice] : a.n_samples);
+    const uint32_t sample_begin = a.sample_begin + (a.n_slices > 1 ? (uint32_t)a.slice_j0[slice] * a.sample_stride : 0u);
+    float *const canvas = slice == 0 ? a.canvas : a.partial + (size_t)(slice - 1) * (size_t)(a.height * a.width) * 3;
+    const bool fresh = slice == 0 ? a.fresh != 0 : true;
     const int B = a.max_bounces;
 
-    uint32_t segs = in_canvas ? 1u : 0u;                   // the fp64 primary search below (a lane runs < 2^32 searches per launch)
+    uint32_t segs = in_canvas && slice == 0 ? 1u : 0u;     // the fp64 primary search below, counted once per launch (a lane runs < 2^32 searches per launch)
     // what bounds this kernel: 16-byte per-lane gathers (one per node visited, three per object record).
     // Counted per lane, summed per wave at the end, next to the segment counter (pt_bvh_counters, include/pt.h).
     uint32_t n_nodes_visited = 0, n_records = 0, n_padding = 0;
@@ -711,7 +718,7 @@ __global__ __launch_bounds__(BVH_BLOCK) void trace_bvh_kernel(TraceArgs a)
 #define PT_STAT(x) (void)0
 #endif   // (n_padding: the part of n_records spent on the empty slot of odd leaves)
     f3 acc = mk3(0.f, 0.f, 0.f);
-    if (in_canvas && !a.fresh) acc = mk3(a.canvas[3 * (size_t)pc + 0], a.canvas[3 * (size_t)pc + 1], a.canvas[3 * (size_t)pc + 2]);
+    if (in_canvas && !fresh) acc = mk3(canvas[3 * (size_t)pc + 0], canvas[3 * (size_t)pc + 1], canvas[3 * (size_t)pc + 2]);
 
     // primary segment, once per pixel, fp64 (src/Lib.hs:41-51, :81-98)
     const PrimaryHit ph = primary_hit(a, pi, pj, stack, BLOCK);
@@ -739,7 +746,7 @@ __global__ __launch_bounds__(BVH_BLOCK) void trace_bvh_kernel(TraceArgs a)
 
     f3 o = cP0, d = cd0, thr = ccol;
     int last = cidx, b = 1;
-    uint32_t gs = a.sample_begin;
+    uint32_t gs = sample_begin;
     int cur = tid;                                         // the pixel (workgroup-relative) this lane works on
     auto scatter = [&](int idx, float e, f3 din, int bounce, f3 at) -> f3 {
         uint32_t r0, r1;
@@ -871,7 +878,7 @@ __global__ __launch_bounds__(BVH_BLOCK) void trace_bvh_kernel(TraceArgs a)
             {
                 if (go_on) {
                     const bool restart = want;             // a new sample from the (current) pixel's primary hit,
-                    if (restart) gs = a.sample_begin + sn * a.sample_stride;
+                    if (restart) gs = sample_begin + sn * a.sample_stride;
                     // whose constants live in LDS, not in registers: the walk needs the registers (occupancy)
                     const float4 p0 = s_pix[cur * 3 + 0], p1 = s_pix[cur * 3 + 1], p2 = s_pix[cur * 3 + 2];
                     const int   idx = restart ? __float_as_int(p2.y) : k;
@@ -973,9 +980,9 @@ __global__ __launch_bounds__(BVH_BLOCK) void trace_bvh_kernel(TraceArgs a)
     // complete in order -- the other three waves may still be tracing)
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     if (in_canvas) {
-        a.canvas[3 * (size_t)pc + 0] = s_acc[tid * 3 + 0];
-        a.canvas[3 * (size_t)pc + 1] = s_acc[tid * 3 + 1];
-        a.canvas[3 * (size_t)pc + 2] = s_acc[tid * 3 + 2];
+        canvas[3 * (size_t)pc + 0] = s_acc[tid * 3 + 0];
+        canvas[3 * (size_t)pc + 1] = s_acc[tid * 3 + 1];
+        canvas[3 * (size_t)pc + 2] = s_acc[tid * 3 + 2];
     }
     unsigned long long wsegs = segs, wnodes = n_nodes_visited, wrecs = n_records, wpad = n_padding;
 #ifdef PT_BVH_STATS
@@ -1019,6 +1026,17 @@ __global__ __launch_bounds__(256) void primary_fill_kernel(TraceArgs a)
     }
     const unsigned long long n = __builtin_popcountll(__ballot(pc < npix));
     if ((threadIdx.x & 63) == 0 && n) atomicAdd(seg_lane(a.segments), n);
+}
+
+// (the same float by float, for canvases whose length is not a multiple of four)
+__global__ __launch_bounds__(256) void slice_sum_scalar_kernel(float *__restrict__ canvas, const float *__restrict__ partial,
+                                                               size_t n, int planes)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float v = canvas[i];
+    for (int p = 0; p < planes; ++p) v += partial[(size_t)p * n + i];
+    canvas[i] = v;
 }
 
 // canvas += plane 0 + plane 1 + ... (in this order): the sample slices of one launch
@@ -1113,7 +1131,17 @@ static hipError_t launch_trace_ns(TraceArgs a, const float4 *geom_host, bool reu
                 // 16-bit entries; 32-bit entries held the kernel to 19 waves per CU, now its 78 VGPRs do: 24) + the
                 // "search over" entry at the bottom.
                 const bool s16 = a.n_nodes < 65536 && !getenv("PT_BVH_STACK32");   // (PT_BVH_STACK32: the 32-bit form for any tree, A/B and tests)
-                const dim3 bgrid((npix + BVH_BLOCK - 1) / BVH_BLOCK), bblock(BVH_BLOCK);
+                // sample slices, as for trace_static_kernel above: the last 1/PT_BVH_SLICE_DIV of a long launch's samples
+                // as a second slice behind the first (a one-wave workgroup of a 4K / 512-spp launch lives ~25 ms of the
+                // launch's 130: without it the launch ends on a long ragged tail)
+                const int ns = a.n_samples;
+                a.n_slices = 1; a.slice_j0[0] = 0; a.slice_n[0] = ns;
+                static const int slice_div = getenv("PT_BVH_SLICE_DIV") ? atoi(getenv("PT_BVH_SLICE_DIV")) : 16;
+                if (a.partial && ns >= BVH_SLICE_MIN_SAMPLES && slice_div > 1) {
+                    a.n_slices = 2;
+                    a.slice_n[1] = ns / slice_div; a.slice_n[0] = ns - a.slice_n[1]; a.slice_j0[1] = a.slice_n[0];
+                }
+                const dim3 bgrid((npix + BVH_BLOCK - 1) / BVH_BLOCK, a.n_slices), bblock(BVH_BLOCK);
                 // PT_BVH_EXTRA_LDS=<bytes>: unused LDS per workgroup, to lower the waves per CU (occupancy experiment)
                 static const size_t bvh_extra_lds = getenv("PT_BVH_EXTRA_LDS") ? (size_t)atoi(getenv("PT_BVH_EXTRA_LDS")) : 0;
                 const size_t bsm = bvh_extra_lds + (size_t)(a.bvh_depth + 2) * BVH_BLOCK * (s16 ? sizeof(uint16_t) : sizeof(int));
@@ -1123,7 +1151,19 @@ static hipError_t launch_trace_ns(TraceArgs a, const float4 *geom_host, bool reu
                 if (s16) { if (spec) PT_BVH_LAUNCH(true, uint16_t); else PT_BVH_LAUNCH(false, uint16_t); }
                 else     { if (spec) PT_BVH_LAUNCH(true, int);      else PT_BVH_LAUNCH(false, int); }
 #undef PT_BVH_LAUNCH
-                return hipGetLastError();
+                hipError_t e = hipGetLastError();
+                if (e == hipSuccess && a.n_slices > 1) {
+                    const size_t nf = (size_t)npix * 3;                // (float4-wise where the plane's length allows, else float-wise)
+                    if (nf % 4 == 0)
+                        hipLaunchKernelGGL(slice_sum_kernel, dim3((unsigned)((nf / 4 + 255) / 256)), dim3(256), 0, s,
+                                           reinterpret_cast<float4 *>(a.canvas), reinterpret_cast<const float4 *>(a.partial), nf / 4,
+                                           a.n_slices - 1);
+                    else
+                        hipLaunchKernelGGL(slice_sum_scalar_kernel, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, s,
+                                           a.canvas, a.partial, nf, a.n_slices - 1);
+                    e = hipGetLastError();
+                }
+                return e;
             }
             if (spec) hipLaunchKernelGGL((trace_steal_kernel<NS, true>), tgrid, tblock, ssm, s, a, sg, a.geom);
             else      hipLaunchKernelGGL((trace_steal_kernel<NS, false>), tgrid, tblock, ssm, s, a, sg, a.geom);

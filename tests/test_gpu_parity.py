@@ -810,3 +810,25 @@ def test_box_test_of_the_spatial_index_never_misses(pa, small):
         assert exact.sum() > n // 8                                                   # the case is exercised
         false_pos.append(float(((dev == 1) & ~exact).sum()) / n)
     assert max(false_pos) < 0.05, false_pos                                           # and the test still prunes
+
+
+def test_indexed_kernel_sample_slices(pa):
+    """A launch of >= 256 samples on an indexed scene runs as two sample slices (the last 1/16 behind the rest, in a
+    plane of its own that is added afterwards: DESIGN.md 3.4); it must trace exactly the samples that two unsliced
+    launches of half the size trace -- the same segment count but for the second launch's primary pass, and the same
+    canvas up to fp32 summation order -- and an additive third launch must continue the same sample sequence."""
+    objs = pa.random_disk_scene(1025, 10)
+    H, W = 96, 80
+    with pa.Renderer(pa.Params(H, W, 500.0, 256, 6), objs, seed=5) as r:
+        r.trace(256)
+        a, sa = r.read_sum_f32(), r.segments
+        r.trace(64)                                           # unsliced, on top
+        a2, sa2 = r.read_sum_f32(), r.segments
+    with pa.Renderer(pa.Params(H, W, 500.0, 256, 6), objs, seed=5) as r:
+        r.trace(128); r.trace(128)
+        b, sb = r.read_sum_f32(), r.segments
+        r.trace(64)
+        b2, sb2 = r.read_sum_f32(), r.segments
+    assert sa + H * W == sb and sa2 + H * W == sb2
+    assert np.allclose(a, b, rtol=1e-5, atol=1e-4) and np.allclose(a2, b2, rtol=1e-5, atol=1e-4)
+    assert a.sum() > 0
