@@ -665,6 +665,14 @@ __global__ __launch_bounds__(NS == -2 ? 64 : TRACE_BLOCK) void trace_steal_kerne
 // nine v_fma_mix_f32 on centre / half-extent nodes, one 16-byte global load per node through a scalar base and a
 // 32-bit offset, a stack pointer instead of a depth, index 0 as the "search over" mark at the bottom of the stack.
 constexpr int BVH_BLOCK = 64;
+// Registers are allocated for SIX waves per SIMD, stated: the stacks and per-pixel records in LDS allow 25 waves per
+// CU, so 80 VGPRs is the budget that matters.  Left to itself the compiler's choice moved with unrelated edits -- 72
+// VGPRs (a seventh wave that LDS does not admit, and 7 % slower) for one variant and 84-86 (five waves) for another
+// after the sample slices went in; with the target stated: 18.3 / 23.4 / 69.8 ms against 19.8 / 25.2 / 76.5 without and
+// 19.2 / 24.4 / 71.3 with (7,7) (profiles/r03_bvh_walk.txt 9).
+#ifndef PT_BVH_WAVES_ATTR
+#define PT_BVH_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(6, 6)))
+#endif
 #ifndef PT_BVH_ROUND_VISITS
 #define PT_BVH_ROUND_VISITS 8
 #endif
@@ -675,7 +683,7 @@ constexpr int BVH_BLOCK = 64;
 // REC32: the compact object records (TraceArgs::bvh_geom32) -- two 16-byte gathers per record instead of three; an
 // object is then named by its position in bvh_prims, and materials / rectangle sides come in that order.
 template <bool SPEC, typename STK, bool REC32>
-__global__ __launch_bounds__(BVH_BLOCK) void trace_bvh_kernel(TraceArgs a)
+__global__ __launch_bounds__(BVH_BLOCK) PT_BVH_WAVES_ATTR void trace_bvh_kernel(TraceArgs a)
 {
     constexpr int BLOCK = BVH_BLOCK;
     // dynamic LDS: the stacks, (bvh_depth + 2) entries x BLOCK lanes x STK, laid out [entry][lane]; entry 0 holds
