@@ -419,9 +419,15 @@ __device__ __forceinline__ bool slab_hit(float4 nd, float ox, float oy, float oz
 {
     typedef _Float16 h2 __attribute__((ext_vector_type(2)));
     const h2 a = __builtin_bit_cast(h2, nd.x), b = __builtin_bit_cast(h2, nd.y), c = __builtin_bit_cast(h2, nd.z);
-    const float mx = __builtin_fmaf((float)a.x, 1.0f, -ox) * r.ix;
-    const float my = __builtin_fmaf((float)a.y, 1.0f, -oy) * r.iy;
-    const float mz = __builtin_fmaf((float)b.x, 1.0f, -oz) * r.iz;
+    // c - o as ONE v_fma_mix_f32 each (c * 1.0 - o, the binary16 centre converted inside the FMA: the same bits as a
+    // conversion and a subtraction, which is what the compiler makes of the C expression -- it folds the multiplication
+    // by one away and with it the instruction that converts for free)
+    float sx, sy, sz;
+    asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel_hi:[1,0,0]" : "=v"(sx) : "v"(nd.x), "v"(ox));
+    asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(sy) : "v"(nd.x), "v"(oy));
+    asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel_hi:[1,0,0]" : "=v"(sz) : "v"(nd.y), "v"(oz));
+    const float mx = sx * r.ix, my = sy * r.iy, mz = sz * r.iz;
+    (void)a;
     const float ax = __builtin_fabsf(r.ix), ay = __builtin_fabsf(r.iy), az = __builtin_fabsf(r.iz);
     const float nx = __builtin_fmaf(-(float)b.y, ax, mx), fx = __builtin_fmaf((float)b.y, ax, mx);
     const float ny = __builtin_fmaf(-(float)c.x, ay, my), fy = __builtin_fmaf((float)c.x, ay, my);
